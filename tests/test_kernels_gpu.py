@@ -1,0 +1,297 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against a plain fp32/fp64 PyTorch
+restatement of the same op on identical (bf16-rounded) inputs.  Tolerances are written next to each check:
+bf16 outputs carry 2^-9 relative rounding, fp32-accumulated contractions of K terms ~1e-3 of the output scale.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gen  # noqa: E402  (tests/golden on sys.path via conftest)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vipant_amd import _ffi, ops as O
+    _ffi.call("vipant_device_check")
+    return O
+
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {err.max():.4e} "
+                             f"(ref scale {ref.abs().max():.3e}); first at {idx}: got {got[tuple(idx)]:.6f} ref {ref[tuple(idx)]:.6f}")
+
+
+# ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(992, 768, 768), (256, 256, 64), (1000, 2304, 768), (516, 512, 1536), (4096, 3072, 768),
+                                   (33, 768, 3072)])
+def test_gemm_nt_plain(ops, M, N, K):
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16); b = rnd(N, K, seed=2, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=3)
+    ref = a.float() @ b.float().t() + bias
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, c, bias=bias, epi=ops.EPI_BF16)
+    assert_close(c, ref, 1e-2, 2e-2, "bf16 epilogue")
+    c32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(a, b, c32, bias=bias, epi=ops.EPI_F32)
+    assert_close(c32, ref, 1e-4, 2e-3, "f32 epilogue")
+    ops.gemm_nt(a, b, c32, epi=ops.EPI_SCALE_F32, alpha=0.37)
+    assert_close(c32, 0.37 * (a.float() @ b.float().t()), 1e-4, 2e-3, "scale epilogue")
+
+
+def test_gemm_nt_identity_layout(ops):
+    """A = I with an asymmetric B catches a transposed / permuted C write."""
+    K = 256
+    a = torch.eye(K, device=DEV, dtype=torch.bfloat16)
+    b = (torch.arange(512 * K, device=DEV, dtype=torch.float32).reshape(512, K) % 251 - 125).to(torch.bfloat16)
+    c = torch.empty(K, 512, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(a, b, c, epi=ops.EPI_F32)
+    assert_close(c, b.float().t(), 0, 0, "identity")
+
+
+def test_gemm_nt_fused_epilogues(ops):
+    M, N, K = 1000, 3072, 768
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16); b = rnd(N, K, seed=2, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=3)
+    pre = a.float() @ b.float().t() + bias
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); g = torch.empty_like(u)
+    ops.gemm_nt(a, b, g, bias=bias, aux=u, epi=ops.EPI_QUICKGELU)
+    assert_close(u, pre, 1e-2, 2e-2, "quickgelu.u")
+    assert_close(g, pre * torch.sigmoid(1.702 * pre), 1e-2, 2e-2, "quickgelu.g")
+    # residual, in place
+    M, N, K = 992, 768, 3072
+    a = rnd(M, K, seed=4, dtype=torch.bfloat16); b = rnd(N, K, seed=5, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=6); res = rnd(M, N, seed=7)
+    ref = a.float() @ b.float().t() + bias + res
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(a, b, out, bias=bias, aux=res, epi=ops.EPI_RESIDUAL_F32)
+    assert_close(out, ref, 1e-4, 3e-3, "residual")
+    r2 = res.clone()
+    ops.gemm_nt(a, b, r2, bias=bias, aux=r2, epi=ops.EPI_RESIDUAL_F32)
+    assert_close(r2, ref, 1e-4, 3e-3, "residual in place")
+    # dQuickGELU
+    M, N, K = 700, 3072, 768
+    a = rnd(M, K, seed=8, dtype=torch.bfloat16); b = rnd(N, K, seed=9, dtype=torch.bfloat16, scale=K ** -0.5)
+    uu = rnd(M, N, seed=10, dtype=torch.bfloat16, scale=2.0)
+    acc = a.float() @ b.float().t()
+    sg = torch.sigmoid(1.702 * uu.float())
+    ref = acc * (sg * (1 + 1.702 * uu.float() * (1 - sg)))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, out, aux=uu, epi=ops.EPI_DQUICKGELU)
+    assert_close(out, ref, 1e-2, 2e-2, "dquickgelu")
+
+
+def test_gemm_nt_strided_rows(ops):
+    """cls-row read-out: A rows taken with a large row stride."""
+    S, D = 31, 768
+    x = rnd(8 * S, D, seed=11, dtype=torch.bfloat16)
+    a = x.view(8, S * D)[:, :D]
+    b = rnd(512, D, seed=12, dtype=torch.bfloat16, scale=D ** -0.5)
+    c = torch.empty(8, 512, device=DEV)
+    ops.gemm_nt(a, b, c, epi=ops.EPI_F32)
+    assert_close(c, a.float() @ b.float().t(), 1e-4, 2e-3, "strided A")
+
+
+# ------------------------------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("M,P,Q", [(992, 768, 768), (64, 256, 256), (100, 16, 512), (5000, 2304, 768), (4096, 768, 3072),
+                                   (129, 129 // 8 * 8, 512)])
+def test_gemm_tn(ops, M, P, Q):
+    a = rnd(M, P, seed=1, dtype=torch.bfloat16); b = rnd(M, Q, seed=2, dtype=torch.bfloat16)
+    ref = a.float().t() @ b.float()
+    c = torch.empty(P, Q, device=DEV)
+    ops.gemm_tn(a, b, c)
+    assert_close(c, ref, 1e-4, 2e-3 * math.sqrt(M), "tn")
+    c2 = torch.full((P, Q), 1.5, device=DEV)
+    ops.gemm_tn(a, b, c2, accumulate=True)
+    assert_close(c2, ref + 1.5, 1e-4, 2e-3 * math.sqrt(M), "tn accumulate")
+
+
+def test_gemm_tn_layout(ops):
+    """One-hot rows: C[p, q] = B[m(p), q] catches any permutation inside the transposed reads."""
+    M, P, Q = 256, 256, 256
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(3))
+    a = torch.zeros(M, P, dtype=torch.bfloat16, device=DEV)
+    a[torch.arange(M), perm.to(DEV)] = 1.0
+    b = (torch.arange(M * Q, device=DEV, dtype=torch.float32).reshape(M, Q) % 253 - 126).to(torch.bfloat16)
+    c = torch.empty(P, Q, device=DEV)
+    ops.gemm_tn(a, b, c)
+    assert_close(c, a.float().t() @ b.float(), 0, 0, "tn one-hot")
+
+
+def test_colsum(ops):
+    for M, N in ((992, 768), (5000, 3072), (3, 2304)):
+        x = rnd(M, N, seed=1, dtype=torch.bfloat16)
+        out = torch.empty(N, device=DEV)
+        ops.colsum(x, out)
+        assert_close(out, x.float().sum(0), 1e-5, 1e-3 * math.sqrt(M), "colsum")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(992, 768), (77 * 3, 512), (5, 1024), (4100, 768)])
+def test_layernorm(ops, M, D):
+    x = rnd(M, D, seed=1, scale=2.0) + 0.3
+    gm = rnd(D, seed=2, scale=0.1) + 1.0; bt = rnd(D, seed=3, scale=0.1)
+    y, y32, mean, rstd = ops.layernorm_fwd(x, gm, bt, want_f32=True)
+    xr = x.double().requires_grad_()
+    gmr, btr = gm.double().requires_grad_(), bt.double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr, (D,), gmr, btr, 1e-5)
+    assert_close(y32, ref, 1e-5, 1e-5, "ln fwd f32")
+    assert_close(y, ref, 1e-2, 1e-2, "ln fwd bf16")
+    dy = rnd(M, D, seed=4, dtype=torch.bfloat16)
+    dres = rnd(M, D, seed=5)
+    ref.backward(dy.double())
+    dx = torch.empty(M, D, device=DEV); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dg = torch.empty(D, device=DEV); db = torch.empty(D, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, gm, dres=dres, dx=dx, dx_bf16=dxb, dgamma=dg, dbeta=db)
+    assert_close(dx, xr.grad + dres.double(), 1e-4, 1e-4, "ln bwd dx")
+    assert_close(dxb, xr.grad + dres.double(), 1e-2, 1e-2, "ln bwd dx bf16")
+    assert_close(dg, gmr.grad, 1e-4, 1e-3 * math.sqrt(M), "ln bwd dgamma")
+    assert_close(db, btr.grad, 1e-4, 1e-3 * math.sqrt(M), "ln bwd dbeta")
+    # fp32 dy, no residual, in-place capable
+    dy32 = rnd(M, D, seed=6)
+    xr.grad = None
+    torch.nn.functional.layer_norm(xr, (D,), gmr, btr, 1e-5).backward(dy32.double())
+    ops.layernorm_bwd(dy32, x, mean, rstd, gm, dx=dx, dgamma=dg, dbeta=db)
+    assert_close(dx, xr.grad, 1e-4, 1e-4, "ln bwd dx (f32 dy)")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def ref_attention(qkv, batch, S, H, causal):
+    D = H * 64
+    q, k, v = qkv.double().view(batch, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((S, S), float("-inf"), device=s.device, dtype=s.dtype).triu_(1)
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(batch * S, D)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("batch,S,H,causal", [(2, 31, 12, False), (3, 316, 12, False), (2, 77, 8, True), (2, 50, 12, False),
+                                              (1, 16, 1, False), (2, 306, 12, False), (3, 20, 8, True)])
+def test_mha(ops, batch, S, H, causal):
+    D = H * 64
+    qkv = rnd(batch * S, 3 * D, seed=1, dtype=torch.bfloat16, scale=1.5)
+    out, lse = ops.mha_fwd(qkv, batch, S, H, causal)
+    qr = qkv.double().requires_grad_()
+    ref, rlse = ref_attention(qr, batch, S, H, causal)
+    assert_close(out, ref, 1e-2, 1e-2, "mha fwd")
+    assert_close(lse, rlse, 1e-4, 1e-3, "mha lse")
+    dout = rnd(batch * S, D, seed=2, dtype=torch.bfloat16)
+    ref.backward(dout.double())
+    dqkv = ops.mha_bwd(qkv, out, dout, lse, batch, S, H, causal)
+    scale = qr.grad.abs().max().item()
+    assert_close(dqkv, qr.grad, 2e-2, 2e-2 * scale, "mha bwd")
+
+
+def test_mha_spiky_scores(ops):
+    """A dominant key per query (exact-softmax path must not lose it to rounding / masking)."""
+    batch, S, H = 1, 316, 1
+    qkv = rnd(S, 192, seed=3, dtype=torch.bfloat16, scale=0.2)
+    qkv[:, 64:128][7] = qkv[:, :64][100] * 40      # key 7 aligned with query 100
+    out, lse = ops.mha_fwd(qkv, batch, S, H, False)
+    ref, rlse = ref_attention(qkv, batch, S, H, False)
+    assert_close(out, ref, 1e-2, 1e-2, "mha spiky")
+    assert_close(lse, rlse, 1e-4, 1e-3, "mha spiky lse")
+
+
+# ------------------------------------------------------------------------------------------ layout helpers
+def test_cast_transpose(ops):
+    for R, C in ((768, 3072), (2304, 768), (100, 36), (768, 512)):
+        w = rnd(R, C, seed=1)
+        d, dt = ops.cast_bf16(w, True)
+        assert torch.equal(d, w.to(torch.bfloat16)) and torch.equal(dt, w.to(torch.bfloat16).t().contiguous())
+
+
+def test_l2norm(ops):
+    x = rnd(37, 512, seed=1)
+    y = ops.l2_normalize(x)
+    assert_close(y, x / x.norm(dim=-1, keepdim=True), 1e-6, 1e-7, "l2norm")
+
+
+# ------------------------------------------------------------------------------------------ InfoNCE
+def nce_inputs(B):
+    a = gen.det_randn(f"nce/a/{B}", (B, 512)); a = a / a.norm(dim=-1, keepdim=True)
+    t = gen.det_randn(f"nce/t/{B}", (B, 512)); t = t / t.norm(dim=-1, keepdim=True)
+    t = t + 0.5 * a; t = t / t.norm(dim=-1, keepdim=True)
+    return a, t
+
+
+@pytest.mark.parametrize("B", [8, 32, 129])
+@pytest.mark.parametrize("tag", ["", "_clamp", "_hot"])
+def test_infonce_golden(ops, golden, B, tag):
+    """K8 boundary against vectors produced by the reference's CELossHead: loss within 1e-3 (north-star
+    tolerance; observed ~1e-5), gradients within 1 % of their scale (bf16 MFMA operands in the backward)."""
+    g = golden(f"infonce_B{B}{tag}")
+    a, t = nce_inputs(B)
+    a_, t_ = a.to(DEV).requires_grad_(), t.to(DEV).requires_grad_()
+    ls = torch.tensor(float(g["logit_scale"]), device=DEV, requires_grad=True)
+    loss = ops.InfoNCEFn.apply(a_, t_, ls, float(g["scale_max"]), 0, B, 1.0)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-3, (float(loss), float(g["loss"]))
+    assert abs(float(loss) - float(g["loss"])) < 5e-5 * max(1.0, abs(float(g["loss"]))), "fp32-level agreement expected"
+    da, dt = torch.from_numpy(g["da"]), torch.from_numpy(g["dt"])
+    # softmax_row + softmax_col - 2I cancels to fp32 rounding on a saturated diagonal: absolute floor ~ eps * s
+    floor = 3e-7 * math.exp(float(g["logit_scale"]))
+    assert_close(a_.grad, da, 1e-2, 1e-2 * da.abs().max().item() + floor, "dx1")
+    assert_close(t_.grad, dt, 1e-2, 1e-2 * dt.abs().max().item() + floor, "dx2")
+    assert abs(float(ls.grad) - float(g["dls"])) < 1e-4 + 1e-3 * abs(float(g["dls"])), (float(ls.grad), float(g["dls"]))
+
+
+@pytest.mark.parametrize("B,row0,nrows", [(512, 0, 512), (1000, 0, 1000), (1024, 256, 256), (4096, 3584, 512)])
+def test_infonce_large_and_sliced(ops, B, row0, nrows):
+    from oracle import ref_cpu as R
+    a = rnd(B, 512, seed=1); a = a / a.norm(dim=-1, keepdim=True)
+    t = rnd(B, 512, seed=2); t = t / t.norm(dim=-1, keepdim=True)
+    t = t + 0.7 * a; t = t / t.norm(dim=-1, keepdim=True)
+    ls = 3.1
+    loss_ref, da, dt, dls = R.infonce_manual(a.cpu(), t.cpu(), ls, None)
+    a_, t_ = a.clone().requires_grad_(), t.clone().requires_grad_()
+    lsp = torch.tensor(ls, device=DEV, requires_grad=True)
+    loss = ops.InfoNCEFn.apply(a_, t_, lsp, 0.0, row0, nrows, 2.0)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4, (float(loss), float(loss_ref))
+    sl = slice(row0, row0 + nrows)
+    assert_close(a_.grad[sl], 2.0 * da[sl], 1e-2, 2e-2 * da.abs().max().item(), "dx1 slice")
+    assert_close(t_.grad[sl], 2.0 * dt[sl], 1e-2, 2e-2 * dt.abs().max().item(), "dx2 slice")
+    if nrows < B:
+        assert float(a_.grad[:row0].abs().max()) == 0.0
+    assert abs(float(lsp.grad) - 2.0 * float(dls)) < 1e-3 * max(1.0, abs(2.0 * float(dls)))
+
+
+# ------------------------------------------------------------------------------------------ LARS
+def test_lars_golden(ops, golden):
+    from oracle import ref_cpu as R
+    g = golden("lars")
+    ps = [gen.det_randn("lars/w0", (16, 24)), gen.det_randn("lars/w1", (4, 3, 5, 5)), gen.det_randn("lars/b0", (24,)),
+          torch.ones([]) * 2.6593, torch.zeros(6, 6)]
+    ps = [p.to(DEV).contiguous() for p in ps]
+    st = ops.LarsState(ps, [p.ndim > 1 for p in ps])
+    for step in range(12):
+        lw, lb = R.adjust_learning_rate(step, epochs=3, steps_per_epoch=5, warmup_epoch=1, batch_size=64, lr_weight=0.2,
+                                        lr_bias=0.0048)
+        grads = [(gen.det_randn(f"lars/g{i}/{step}", tuple(p.shape)) * (0.0 if i == 4 and step < 2 else 1.0)).to(DEV)
+                 for i, p in enumerate(ps)]
+        st.step(grads, [lw if p.ndim > 1 else lb for p in ps], 1e-6, 0.9, 0.001)
+        if step in (0, 1, 5, 11):
+            for i, p in enumerate(ps):
+                assert_close(p, torch.from_numpy(g[f"p{i}_{step}"]), 1e-5, 1e-6, f"lars p{i} step {step}")

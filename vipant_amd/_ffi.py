@@ -1,0 +1,84 @@
+"""ctypes binding of libvipant_hip.so (the C ABI declared in include/vipant_hip.h).
+
+The product path has NO CPU or eager-PyTorch fallback: if the library is missing or a call fails,
+an exception is raised.  Build the library with `python -m vipant_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvipant_hip.so")
+
+EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32 = range(6)
+
+_p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vipant_hip.h one to one
+PROTOTYPES = {
+    "vipant_last_error": (C.c_char_p, []),
+    "vipant_version": (_i32, []),
+    "vipant_device_check": (_i32, []),
+    "vipant_gemm_nt": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _i64, _i64, _i64, _i32, _p]),
+    "vipant_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vipant_gemm_tn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i32, _p, _sz, _p]),
+    "vipant_colsum_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_colsum_bf16": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _sz, _p]),
+    "vipant_layernorm_fwd": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "vipant_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
+    "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),
+    "vipant_conv_weight_prep": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_im2col": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
+    "vipant_assemble_tokens": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_assemble_tokens_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i64, _i64, _p]),
+    "vipant_conv_weight_grad": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_l2norm_fwd": (_i32, [_p, _p, _p, _i64, _i64, _p]),
+    "vipant_l2norm_bwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "vipant_embed_tokens": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_gather_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_scatter_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_infonce_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_infonce_fwd_bwd": (_i32, [_p, _p, _p, _f32, _p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "vipant_lars_workspace_bytes": (_sz, [_i64]),
+    "vipant_lars_step": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _p, _sz, _p]),
+}
+
+
+class VipantError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VipantError(
+                f"{LIB_PATH} not found: the HIP hot path is not built (run `python -m vipant_amd.build`); "
+                "there is no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)      # AttributeError here = header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke a status-returning entry point; raise VipantError with the library's message on failure."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        msg = lib().vipant_last_error().decode(errors="replace")
+        raise VipantError(f"{name} failed with code {rc}: {msg}")
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(lib(), name)(*args))

@@ -1,0 +1,403 @@
+// Multi-head attention core, head dim 64: softmax(q k^T / 8 [+ causal]) v and its backward
+// (nn.MultiheadAttention inside ResidualAttentionBlock, cvap/module/val.py:511-517).
+//
+// gfx950 design.  Sequences on this path are short (S <= 316 audio tokens, <= 77 text tokens), so one
+// head's whole K and V (<= 40 KiB each in bf16) live in LDS: one workgroup per (batch, head), no online
+// softmax, no second pass over keys.  All products run on v_mfma_f32_16x16x32_bf16 with the QUERY on the
+// MFMA column (lane & 15):
+//     S^T tile  = K_tile . Q^T          (A = K rows from LDS by ds_read_b128, B = Q rows from registers)
+//     O^T tile  = V^T . P^T             (A = V^T by ds_read_b64_tr_b16 transposed reads, B = P in place)
+// The S^T accumulator (keys on registers, query on the lane) is, after exp and bf16 packing, already the
+// B operand of the second product -- no LDS round trip, no cross-lane movement; the k-slot order it implies
+// (slot j<4 -> key tile 2u, j>=4 -> key tile 2u+1) is matched by which rows the transposed reads fetch.
+// Row max / sum need only two xor-shuffles (lanes l, l^16, l^32, l^48 share a query).
+// One LDS image per matrix serves both row reads and transposed reads: 128-B rows, 16-B chunk index
+// XOR-ed with ((row>>1)&3)<<1 (conflict-free for both access kinds); filled by LDS-DMA with the swizzle
+// applied to the source address.  Backward = two passes with the same structure (dQ per query block with
+// K,V resident; dK,dV per key block with Q,dO resident): 40 % more MFMA work than a single-pass scheme but
+// no float atomics, bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SCALE = 0.125f;              // 1/sqrt(64)
+constexpr float C2 = SCALE * LOG2E;
+
+__device__ __forceinline__ int img_swz(int r) { return ((r >> 1) & 3) << 1; }
+
+// Fill a [rows8*8 x 64] bf16 LDS image from `rows8*8` consecutive rows (stride ld_bytes) of a buffer.
+__device__ __forceinline__ void dma_image(char* lds, __amdgpu_buffer_rsrc_t rs, uint32_t ld_bytes, int rows8,
+                                          int wave, int nwaves, int lane) {
+    for (int blk = wave; blk < rows8; blk += nwaves) {
+        const int r = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ img_swz(r);
+        lds_dma16(rs, lds + blk * 1024, (uint32_t)r * ld_bytes + (uint32_t)c * 16, 0);
+    }
+}
+
+// Per-lane byte offsets into an image; everything else is a compile-time constant added on top, because
+// the swizzle term depends only on (row & 7) and tile / k-step bases are multiples of 16 rows.
+struct ImgLane {
+    uint32_t row[2];   // row-read fragment of 16-row tile 0 for d-step 0 / 1
+    uint32_t tr[4];    // transposed fragment, first read, rows 4g+qq of tile 0, d-tile 0..3
+};
+__device__ __forceinline__ ImgLane img_lane(int lane) {
+    ImgLane a;
+    const int r = lane & 15, g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) a.row[ds] = (uint32_t)(r * 128 + (((ds * 4 + g) ^ img_swz(r)) << 4));
+    const int ra = 4 * g + qq;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        a.tr[dt] = (uint32_t)(ra * 128 + (((2 * dt + (pp >> 1)) ^ img_swz(ra)) << 4) + (pp & 1) * 8);
+    return a;
+}
+
+// Row-read fragment (A operand rows / B operand columns): 16 B = row (tile*16 + (lane&15)), k = 32*ds + 8*(lane>>4)..
+__device__ __forceinline__ bf16x8 img_row_frag(const char* img, const ImgLane& a, int tile, int ds) {
+    return *(const bf16x8*)(img + a.row[ds] + tile * 2048);
+}
+
+// Transposed fragment: A[row = 16*dt + (lane&15)][k-slot (g, j)] with slot j<4 -> image row 32u + 4g + j,
+// j>=4 -> image row 32u + 16 + 4g + (j-4).
+__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, const ImgLane& a, int u, int dt) {
+    const bf16x4 lo = lds_read_tr16(img + a.tr[dt] + u * 4096);
+    const bf16x4 hi = lds_read_tr16(img + a.tr[dt] + u * 4096 + 2048);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // over the 4 lanes sharing (lane & 15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct MhaArgs {
+    const bf16_t* qkv; bf16_t* out; float* lse;
+    const bf16_t* dout; float* delta; bf16_t* dqkv;
+    int batch, S, H;
+};
+
+// ------------------------------------------------------------------------------------------- forward
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NT * 16;
+    char* kimg = smem;
+    char* vimg = smem + SP * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, 4, lane);
+    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, 4, lane);
+    __syncthreads();
+
+    const int qcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    for (int qb = wave; qb * 16 < p.S; qb += 4) {
+        const int q = qb * 16 + qcol;
+        const int qrow = q < p.S ? q : p.S - 1;
+        const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
+        const bf16x8 qf0 = *(const bf16x8*)qp;
+        const bf16x8 qf1 = *(const bf16x8*)(qp + 32);
+
+        f32x4 s[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + g * 4 + r;
+                if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
+                m = fmaxf(m, acc[r]);
+            }
+            s[kt] = acc;
+        }
+        m = group_max(m);
+        float l = 0.f;
+        const float mc = m * C2;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] * C2 - mc);
+                s[kt][r] = e;
+                l += e;
+            }
+        l = group_sum(l);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+            const bf16x8 pf = pack8(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg, il, u, dt), pf,
+                                                                o[dt], 0, 0, 0);
+        }
+        if (q < p.S) {
+            const float inv = __frcp_rn(l);
+            bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
+            if (g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- backward, pass A: dQ
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NT * 16;
+    char* kimg = smem;
+    char* vimg = smem + SP * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, 4, lane);
+    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, 4, lane);
+    __syncthreads();
+
+    const int qcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    for (int qb = wave; qb * 16 < p.S; qb += 4) {
+        const int q = qb * 16 + qcol;
+        const int qrow = q < p.S ? q : p.S - 1;
+        const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
+        const bf16x8 qf0 = *(const bf16x8*)qp;
+        const bf16x8 qf1 = *(const bf16x8*)(qp + 32);
+        const int64_t orow = (row_base + qrow) * D + h * 64 + 8 * g;
+        const bf16x8 do0 = *(const bf16x8*)(p.dout + orow);
+        const bf16x8 do1 = *(const bf16x8*)(p.dout + orow + 32);
+        const bf16x8 o0 = *(const bf16x8*)(p.out + orow);
+        const bf16x8 o1 = *(const bf16x8*)(p.out + orow + 32);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)do0[e] * (float)o0[e] + (float)do1[e] * (float)o1[e];
+        dl = group_sum(dl);
+        const int64_t stat = ((int64_t)b * p.H + h) * p.S + qrow;
+        const float nlse = -p.lse[stat] * LOG2E;
+        if (g == 0 && q < p.S) p.delta[stat] = dl;
+
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int u = 0; u < NT / 2; ++u) {
+            f32x4 ds2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * u + t;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 0), do0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 1), do1, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + g * 4 + r;
+                    const bool dead = key >= p.S || (CAUSAL && key > q);
+                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(sa[r] * C2 + nlse);
+                    ds2[t][r] = pr * (dp[r] - dl) * SCALE;
+                }
+            }
+            const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(kimg, il, u, dt), dsf, dq[dt], 0, 0, 0);
+        }
+        if (q < p.S) {
+            bf16_t* dqp = p.dqkv + (row_base + q) * ld + h * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dqp + dt * 16) = f32x4_to_bf16x4(dq[dt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ backward, pass B: dK, dV
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NT * 16;
+    char* qimg = smem;
+    char* doimg = smem + SP * 128;
+    float* slse = (float*)(smem + 2 * SP * 128);   // -lse * log2e per query
+    float* sdel = slse + SP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    const bf16_t* dobase = p.dout + row_base * D + h * 64;
+    const int64_t remain_o = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
+    const uint32_t lim_o = (uint32_t)(remain_o > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain_o);
+    dma_image(qimg, make_rsrc(base, lim), ld * 2, SP / 8, wave, 4, lane);
+    dma_image(doimg, make_rsrc(dobase, lim_o), D * 2, SP / 8, wave, 4, lane);
+    for (int i = threadIdx.x; i < SP; i += 256) {
+        const int64_t stat = ((int64_t)b * p.H + h) * p.S + i;
+        slse[i] = i < p.S ? -p.lse[stat] * LOG2E : 0.f;
+        sdel[i] = i < p.S ? p.delta[stat] : 0.f;
+    }
+    __syncthreads();
+
+    const int kcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    for (int kb = wave; kb * 16 < p.S; kb += 4) {
+        const int key = kb * 16 + kcol;
+        const int krow = key < p.S ? key : p.S - 1;
+        const bf16_t* kp = base + (int64_t)krow * ld + D + 8 * g;
+        const bf16x8 kf0 = *(const bf16x8*)kp;
+        const bf16x8 kf1 = *(const bf16x8*)(kp + 32);
+        const bf16x8 vf0 = *(const bf16x8*)(kp + D);
+        const bf16x8 vf1 = *(const bf16x8*)(kp + D + 32);
+
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+        for (int u = 0; u < NT / 2; ++u) {
+            f32x4 p2[2], ds2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * u + t;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 0), kf0, sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 1), kf1, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 0), vf0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 1), vf1, dp, 0, 0, 0);
+                const f32x4 nl = *(const f32x4*)(slse + qt * 16 + g * 4);
+                const f32x4 dl = *(const f32x4*)(sdel + qt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 16 + g * 4 + r;
+                    const bool dead = q >= p.S || (CAUSAL && key > q);
+                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(sa[r] * C2 + nl[r]);
+                    p2[t][r] = pr;
+                    ds2[t][r] = pr * (dp[r] - dl[r]) * SCALE;
+                }
+            }
+            const bf16x8 pf = pack8(p2[0], p2[1]);
+            const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(doimg, il, u, dt), pf,
+                                                                 dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(qimg, il, u, dt), dsf,
+                                                                 dk[dt], 0, 0, 0);
+            }
+        }
+        if (key < p.S) {
+            bf16_t* dkp = p.dqkv + (row_base + key) * ld + D + h * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *(bf16x4*)(dkp + dt * 16) = f32x4_to_bf16x4(dk[dt]);
+                *(bf16x4*)(dkp + D + dt * 16) = f32x4_to_bf16x4(dv[dt]);
+            }
+        }
+    }
+}
+
+template <int NT, bool CAUSAL>
+int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
+    constexpr int lds = NT * 16 * 128 * 2;
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds, s, a);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+template <int NT, bool CAUSAL>
+int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
+    constexpr int lds_a = NT * 16 * 128 * 2;
+    constexpr int lds_b = NT * 16 * 128 * 2 + NT * 16 * 8;
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        configured = true;
+    }
+    hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds_a, s, a);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((mha_bwd_dkv_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds_b, s, a);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+template <bool CAUSAL, bool BWD>
+int32_t dispatch(const MhaArgs& a, hipStream_t s) {
+#define VIPANT_MHA_CASE(NT) \
+    if (a.S <= NT * 16) return BWD ? launch_bwd<NT, CAUSAL>(a, s) : launch_fwd<NT, CAUSAL>(a, s);
+    VIPANT_MHA_CASE(2) VIPANT_MHA_CASE(4) VIPANT_MHA_CASE(6) VIPANT_MHA_CASE(10) VIPANT_MHA_CASE(14)
+    VIPANT_MHA_CASE(20) VIPANT_MHA_CASE(24)
+#undef VIPANT_MHA_CASE
+    vipant_set_error("mha: sequence length %d > 384 is not supported by the resident-K/V kernel", a.S);
+    return VIPANT_EBADSHAPE;
+}
+
+int32_t check(const void* qkv, int64_t batch, int64_t S, int64_t H) {
+    VIPANT_REQUIRE(batch > 0 && S > 0 && H > 0, VIPANT_EBADSHAPE, "mha: empty problem");
+    VIPANT_REQUIRE((uintptr_t)qkv % 16 == 0, VIPANT_EALIGN, "mha: qkv must be 16-byte aligned");
+    VIPANT_REQUIRE(batch * H < (1ll << 31), VIPANT_EBADSHAPE, "mha: too many (batch, head) problems");
+    return VIPANT_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t vipant_mha_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t batch, int64_t S, int64_t H,
+                                  int32_t causal, void* stream) {
+    if (int32_t e = check(qkv, batch, S, H)) return e;
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H};
+    return causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse,
+                                  float* delta, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H, int32_t causal,
+                                  void* stream) {
+    if (int32_t e = check(qkv, batch, S, H)) return e;
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv,
+              (int)batch, (int)S, (int)H};
+    return causal ? dispatch<true, true>(a, (hipStream_t)stream) : dispatch<false, true>(a, (hipStream_t)stream);
+}

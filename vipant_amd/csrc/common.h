@@ -1,0 +1,99 @@
+// Shared device/host helpers for libvipant_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vipant_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_AS __attribute__((address_space(3)))
+#define WAVE 64
+
+// ---- host side error plumbing -------------------------------------------------------------------
+void vipant_set_error(const char* fmt, ...);
+
+#define VIPANT_HIP_TRY(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            vipant_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                             __LINE__);                                                         \
+            return VIPANT_EHIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define VIPANT_REQUIRE(cond, code, ...)   \
+    do {                                  \
+        if (!(cond)) {                    \
+            vipant_set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define VIPANT_LAUNCH_CHECK()                                                               \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess) {                                                             \
+            vipant_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),     \
+                             __FILE__, __LINE__);                                           \
+            return VIPANT_EHIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers -----------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ bf16x4 f32x4_to_bf16x4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
+// 128-bit buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// One LDS-DMA instruction: each lane copies 16 B from rsrc[voff + soff] to lds_base + lane*16.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, uint32_t voff,
+                                          uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_base, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p);
+}
+
+// XCD-aware bijective remap of a linear block id: blocks id, id+8, ... share an XCD, give each XCD a
+// contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int xcd = id & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+#endif

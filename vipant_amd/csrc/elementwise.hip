@@ -1,0 +1,380 @@
+// HBM-bound layout / elementwise kernels around the contractions: casts (with transpose), patch im2col,
+// token assembly (cls + positional table), L2 normalisation, token-embedding gather, column sums.
+// All use 16-byte accesses per lane on the contiguous dimension and grid-stride loops capped at ~2048
+// workgroups (MI355X: 256 CUs x 8).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXB = 2048;
+inline int grid_for(int64_t work_items, int per_block) {
+    int64_t b = ceil_div(work_items, per_block);
+    return (int)(b > MAXB ? MAXB : (b < 1 ? 1 : b));
+}
+
+// ---- fp32 -> bf16 cast, optional transposed copy (64x64 tiles through LDS) --------------------------------
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        *(bf16x4*)(dst + i * 4) = f32x4_to_bf16x4(*(const f32x4*)(src + i * 4));
+}
+
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             bf16_t* __restrict__ dst_t, int R, int C) {
+    __shared__ bf16_t tile[64][66];
+    const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = tr + r, gc = tc + tx;
+        bf16_t v = (bf16_t)0.0f;
+        if (gr < R && gc < C) {
+            v = (bf16_t)src[(int64_t)gr * C + gc];
+            if (dst != nullptr) dst[(int64_t)gr * C + gc] = v;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int gc = tc + c, gr = tr + tx;
+        if (gc < C && gr < R) dst_t[(int64_t)gc * R + gr] = tile[tx][c];
+    }
+}
+
+// ---- conv1.weight -> GEMM weight ---------------------------------------------------------------------
+__global__ void conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int64_t O, int Cin,
+                                        int khw, int mean_channels) {
+    const int64_t total = mean_channels ? O * khw : O * Cin * khw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mean_channels) {
+            const int64_t o = i / khw, k = i % khw;
+            float s = 0.f;
+            for (int c = 0; c < Cin; ++c) s += w[(o * Cin + c) * khw + k];
+            out[i] = (bf16_t)(s / (float)Cin);
+        } else {
+            out[i] = (bf16_t)w[i];
+        }
+    }
+}
+
+__global__ void conv_weight_grad_kernel(const float* __restrict__ g, float* __restrict__ wgrad, int64_t O, int Cin,
+                                        int khw, int accumulate) {
+    const int64_t total = O * Cin * khw;
+    const float inv = 1.0f / (float)Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = i / ((int64_t)Cin * khw), k = i % khw;
+        const float v = g[o * khw + k] * inv;
+        wgrad[i] = accumulate ? wgrad[i] + v : v;
+    }
+}
+
+// ---- im2col: each thread emits 8 consecutive patch columns (16 B of bf16) ------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int b, int C,
+                                                     int T, int F, int ph, int pw, int sh, int sw, int nrow, int ncol,
+                                                     int vec_ok) {
+    const int kcols = C * ph * pw;
+    const int64_t chunks_per_row = kcols / 8;
+    const int64_t total = (int64_t)b * nrow * ncol * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t prow = i / chunks_per_row;
+        const int k = (int)(i % chunks_per_row) * 8;
+        const int c = k / (ph * pw), ii = (k / pw) % ph, jj = k % pw;
+        const int64_t bi = prow / (nrow * ncol);
+        const int tok = (int)(prow % (nrow * ncol));
+        const int tr = tok / ncol, fc = tok % ncol;
+        const float* src = x + ((bi * C + c) * T + (int64_t)tr * sh + ii) * F + fc * sw + jj;
+        bf16x8 o;
+        if (vec_ok) {
+            const f32x4 a = *(const f32x4*)src, d = *(const f32x4*)(src + 4);
+            o[0] = (bf16_t)a[0]; o[1] = (bf16_t)a[1]; o[2] = (bf16_t)a[2]; o[3] = (bf16_t)a[3];
+            o[4] = (bf16_t)d[0]; o[5] = (bf16_t)d[1]; o[6] = (bf16_t)d[2]; o[7] = (bf16_t)d[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)src[e];
+        }
+        *(bf16x8*)(out + prow * kcols + k) = o;
+    }
+}
+
+// ---- token assembly ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ patches, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, float* __restrict__ tokens, int64_t b,
+                                                       int P, int D) {
+    const int S = P + 1, d4 = D / 4;
+    const int64_t total = b * S * d4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d4) * 4;
+        const int64_t row = i / d4;
+        const int s = (int)(row % S);
+        const int64_t bi = row / S;
+        const f32x4 base = s == 0 ? *(const f32x4*)(cls + c) : *(const f32x4*)(patches + (bi * P + s - 1) * D + c);
+        *(f32x4*)(tokens + row * D + c) = base + *(const f32x4*)(pos + (int64_t)s * D + c);
+    }
+}
+
+// dpatches (bf16) = dtokens rows s >= 1; dpos[s] = sum_b dtokens[b, s]; dcls = dpos row 0 (before accumulate).
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dtok, bf16_t* __restrict__ dpatches,
+                                                           float* dcls, float* dpos, int accumulate, int64_t b, int P,
+                                                           int D) {
+    const int S = P + 1, d4 = D / 4;
+    const int64_t total = (int64_t)S * d4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d4) * 4;
+        const int s = (int)(i / d4);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t bi = 0; bi < b; ++bi) {
+            const f32x4 v = *(const f32x4*)(dtok + (bi * S + s) * D + c);
+            acc += v;
+            if (s > 0) *(bf16x4*)(dpatches + (bi * P + s - 1) * D + c) = f32x4_to_bf16x4(v);
+        }
+        float* dp = dpos + (int64_t)s * D + c;
+        if (s == 0) {
+            float* dc = dcls + c;
+            *(f32x4*)dc = accumulate ? *(const f32x4*)dc + acc : acc;
+        }
+        *(f32x4*)dp = accumulate ? *(const f32x4*)dp + acc : acc;
+    }
+}
+
+// ---- L2 normalisation: one wave per row --------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ norm, int64_t M, int E) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 v = *(const f32x4*)(x + row * E + c);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        const float n = sqrtf(wave_sum(s));
+        const float inv = 1.0f / n;
+        for (int c = lane * 4; c < E; c += 256) *(f32x4*)(y + row * E + c) = *(const f32x4*)(x + row * E + c) * inv;
+        if (lane == 0) norm[row] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ norm, float* __restrict__ dx,
+                                                         bf16_t* __restrict__ dxb, int64_t M, int E) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 g = *(const f32x4*)(dy + row * E + c), v = *(const f32x4*)(y + row * E + c);
+            s += g[0] * v[0] + g[1] * v[1] + g[2] * v[2] + g[3] * v[3];
+        }
+        s = wave_sum(s);
+        const float inv = 1.0f / norm[row];
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 o = (*(const f32x4*)(dy + row * E + c) - *(const f32x4*)(y + row * E + c) * s) * inv;
+            if (dx != nullptr) *(f32x4*)(dx + row * E + c) = o;
+            if (dxb != nullptr) *(bf16x4*)(dxb + row * E + c) = f32x4_to_bf16x4(o);
+        }
+    }
+}
+
+// ---- text: embedding gather + positional table, EOT argmax ---------------------------------------------
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ x,
+                                                           int64_t* __restrict__ eot, int64_t b, int L, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = b * L;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int l = (int)(row % L);
+        const int64_t tok = tokens[row];
+        for (int c = lane * 4; c < D; c += 256)
+            *(f32x4*)(x + row * D + c) = *(const f32x4*)(table + tok * D + c) + *(const f32x4*)(pos + (int64_t)l * D + c);
+        if (l == 0 && lane == 0) {   // first maximal index, as torch.argmax
+            int64_t best = tokens[row];
+            int bi = 0;
+            for (int j = 1; j < L; ++j)
+                if (tokens[row + j] > best) { best = tokens[row + j]; bi = j; }
+            eot[row / L] = bi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t n, int64_t rpi, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        for (int c = lane * 4; c < D; c += 256) *(f32x4*)(out + i * D + c) = *(const f32x4*)(x + r * D + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ dx, int64_t n, int64_t rpi, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        for (int c = lane * 4; c < D; c += 256) {
+            float* d = dx + r * D + c;
+            *(f32x4*)d = *(const f32x4*)d + *(const f32x4*)(g + i * D + c);
+        }
+    }
+}
+
+// ---- column sums over tokens: thread = 8 columns, block = 512 columns x 4 row lanes, grid.y row chunks --
+constexpr int CS_ROWCHUNKS = 128;
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int64_t ldx, float* __restrict__ partial,
+                                                     int64_t M, int N) {
+    __shared__ float red[4][512];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + tx * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col < N) {
+        for (int64_t r = (int64_t)blockIdx.y * 4 + ty; r < M; r += (int64_t)gridDim.y * 4) {
+            const bf16x8 v = *(const bf16x8*)(X + r * ldx + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int c = blockIdx.x * 512 + i;
+        if (c < N) partial[(int64_t)blockIdx.y * N + c] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nchunks, int N, float* out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * N + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+}  // namespace
+
+extern "C" int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t R, int64_t C, void* stream) {
+    VIPANT_REQUIRE(R > 0 && C > 0, VIPANT_EBADSHAPE, "cast_bf16: empty");
+    hipStream_t s = (hipStream_t)stream;
+    if (dst_t == nullptr) {
+        VIPANT_REQUIRE((R * C) % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0, VIPANT_EALIGN,
+                       "cast_bf16: need numel %% 4 == 0 and aligned pointers");
+        const int64_t n4 = R * C / 4;
+        hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16_t*)dst, n4);
+    } else {
+        hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(C, 64), (unsigned)ceil_div(R, 64)), dim3(256), 0,
+                           s, src, (bf16_t*)dst, (bf16_t*)dst_t, (int)R, (int)C);
+    }
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_conv_weight_prep(const float* w, uint16_t* out, int64_t O, int64_t Cin, int64_t khw,
+                                           int32_t mean_channels, void* stream) {
+    VIPANT_REQUIRE(O > 0 && Cin > 0 && khw > 0, VIPANT_EBADSHAPE, "conv_weight_prep: empty");
+    const int64_t total = mean_channels ? O * khw : O * Cin * khw;
+    hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)out, O, (int)Cin, (int)khw, mean_channels);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_conv_weight_grad(const float* g, float* wgrad, int64_t O, int64_t Cin, int64_t khw,
+                                           int32_t accumulate, void* stream) {
+    VIPANT_REQUIRE(O > 0 && Cin > 0 && khw > 0, VIPANT_EBADSHAPE, "conv_weight_grad: empty");
+    hipLaunchKernelGGL(conv_weight_grad_kernel, dim3(grid_for(O * Cin * khw, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       wgrad, O, (int)Cin, (int)khw, accumulate);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_im2col(const float* x, uint16_t* out, int64_t b, int64_t C, int64_t T, int64_t F, int64_t ph,
+                                 int64_t pw, int64_t sh, int64_t sw, void* stream) {
+    VIPANT_REQUIRE(b > 0 && T >= ph && F >= pw && pw % 8 == 0, VIPANT_EBADSHAPE,
+                   "im2col: need T>=ph, F>=pw, pw%%8==0 (T=%ld F=%ld ph=%ld pw=%ld)", (long)T, (long)F, (long)ph, (long)pw);
+    const int nrow = (int)((T - ph) / sh + 1), ncol = (int)((F - pw) / sw + 1);
+    const int vec_ok = (F % 4 == 0 && sw % 4 == 0 && (uintptr_t)x % 16 == 0) ? 1 : 0;
+    const int64_t total = b * nrow * ncol * (C * ph * pw / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out,
+                       (int)b, (int)C, (int)T, (int)F, (int)ph, (int)pw, (int)sh, (int)sw, nrow, ncol, vec_ok);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_assemble_tokens(const float* patches, const float* cls, const float* pos, float* tokens,
+                                          int64_t b, int64_t P, int64_t D, void* stream) {
+    VIPANT_REQUIRE(b > 0 && P > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "assemble_tokens: bad shape");
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(b * (P + 1) * D / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       patches, cls, pos, tokens, b, (int)P, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_assemble_tokens_bwd(const float* dtokens, uint16_t* dpatches, float* dcls, float* dpos,
+                                              int32_t accumulate, int64_t b, int64_t P, int64_t D, void* stream) {
+    VIPANT_REQUIRE(b > 0 && P > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "assemble_tokens_bwd: bad shape");
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(grid_for((P + 1) * D / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dtokens, (bf16_t*)dpatches, dcls, dpos, accumulate, b, (int)P, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_l2norm_fwd(const float* x, float* y, float* norm, int64_t M, int64_t E, void* stream) {
+    VIPANT_REQUIRE(M > 0 && E > 0 && E % 4 == 0, VIPANT_EBADSHAPE, "l2norm_fwd: bad shape");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, norm, M, (int)E);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx, uint16_t* dx_bf16,
+                                     int64_t M, int64_t E, void* stream) {
+    VIPANT_REQUIRE(M > 0 && E > 0 && E % 4 == 0, VIPANT_EBADSHAPE, "l2norm_bwd: bad shape");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, dy, y, norm, dx,
+                       (bf16_t*)dx_bf16, M, (int)E);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_embed_tokens(const int64_t* tokens, const float* table, const float* pos, float* x, int64_t* eot,
+                                       int64_t b, int64_t L, int64_t D, void* stream) {
+    VIPANT_REQUIRE(b > 0 && L > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "embed_tokens: bad shape");
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for(b * L, 4)), dim3(256), 0, (hipStream_t)stream, tokens, table, pos,
+                       x, eot, b, (int)L, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_gather_rows(const float* x, const int64_t* idx, float* out, int64_t n, int64_t rows_per_item,
+                                      int64_t D, void* stream) {
+    VIPANT_REQUIRE(n > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "gather_rows: bad shape");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, x, idx, out, n,
+                       rows_per_item, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_scatter_rows(const float* g, const int64_t* idx, float* dx, int64_t n, int64_t rows_per_item,
+                                       int64_t D, void* stream) {
+    VIPANT_REQUIRE(n > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "scatter_rows: bad shape");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, g, idx, dx, n,
+                       rows_per_item, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" size_t vipant_colsum_workspace_bytes(int64_t M, int64_t N) {
+    (void)M;
+    return (size_t)CS_ROWCHUNKS * (size_t)N * sizeof(float);
+}
+
+extern "C" int32_t vipant_colsum_bf16(const uint16_t* X, int64_t ldx, float* out, int64_t M, int64_t N, int32_t accumulate,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, VIPANT_EBADSHAPE, "colsum: need N%%8==0, ldx%%8==0");
+    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_colsum_workspace_bytes(M, N), VIPANT_ENOWORKSPACE,
+                   "colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = (int)(ceil_div(M, 4) < CS_ROWCHUNKS ? ceil_div(M, 4) : CS_ROWCHUNKS);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(N, 512), chunks), dim3(256), 0, s, (const bf16_t*)X, ldx,
+                       (float*)workspace, M, (int)N);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float*)workspace,
+                       chunks, (int)N, out, accumulate);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}

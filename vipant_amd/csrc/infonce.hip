@@ -1,0 +1,291 @@
+// Symmetric InfoNCE (CELossHead.forward, cvap/module/decoder/loss_head.py:265-284):
+//   s = min(exp(logit_scale), scale_max);  Z = s * x1 x2^T;  loss = mean_i CE(Z[i,:], i) + mean_i CE(Z[:,i], i).
+//
+// gfx950 design: the B x B logits are never written to HBM.
+//   pass 1  256x256 logit tiles on MFMA (the shared NT main loop); the epilogue reduces each tile to per-row
+//           and per-column (max, sum exp, sum exp*z) triples with wave shuffles and stores only those
+//           (B * #tiles floats instead of B^2) plus the diagonal;
+//   final   one small kernel merges the triples into row / column log-sum-exp, the loss and d logit_scale
+//           ( = sum dZ * Z, expressible from the triples );
+//   pass 2  recomputes the tiles that touch this rank's row strip / column strip, forms
+//           s * dZ = s * (softmax_row + softmax_col - 2 I) / B in registers and stores it as bf16;
+//   grads   dx1 = (s dZ) x2 and dx2 = (s dZ)^T x1 reuse the NT / TN contraction kernels.
+// Precision: inputs are fp32; the logit contraction uses a hi/lo bf16 split (x = hi + lo, three MFMA terms
+// hi*hi + hi*lo + lo*hi concatenated along K) with fp32 accumulation, which keeps |dZ| below ~1e-5 relative and
+// the loss well inside the 1e-3 budget; exp / log in fp32.
+#include "nt_core.h"
+
+namespace {
+
+using namespace ntcore;
+
+struct NceWs {       // carved out of the caller's workspace; all offsets 256-B aligned
+    bf16_t *x1cat, *x2cat, *x2t, *dz;
+    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal;   // scal[0] = s, scal[1] = clamped
+    void* tn_ws;
+    size_t tn_bytes, total;
+    int Bp, rparts, cparts;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+NceWs carve(char* base, int64_t B, int64_t E) {
+    NceWs w;
+    const int64_t Bp = (B + 63) / 64 * 64;
+    const int ntm = (int)ceil_div(B, BM), ntn = (int)ceil_div(B, BN);
+    w.Bp = (int)Bp; w.rparts = ntn * 4; w.cparts = ntm * 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += align256(bytes); return p; };
+    w.x1cat = (bf16_t*)take((size_t)B * 3 * E * 2);
+    w.x2cat = (bf16_t*)take((size_t)B * 3 * E * 2);
+    w.x2t = (bf16_t*)take((size_t)E * Bp * 2);
+    w.dz = (bf16_t*)take((size_t)B * Bp * 2);
+    w.rmax = (float*)take((size_t)w.rparts * B * 4); w.rsum = (float*)take((size_t)w.rparts * B * 4);
+    w.rwz = (float*)take((size_t)w.rparts * B * 4);
+    w.cmax = (float*)take((size_t)w.cparts * B * 4); w.csum = (float*)take((size_t)w.cparts * B * 4);
+    w.cwz = (float*)take((size_t)w.cparts * B * 4);
+    w.diag = (float*)take((size_t)B * 4); w.rlse = (float*)take((size_t)B * 4); w.clse = (float*)take((size_t)B * 4);
+    w.scal = (float*)take(256);
+    w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
+    w.tn_ws = take(w.tn_bytes);
+    w.total = off;
+    return w;
+}
+
+// x -> [hi | hi | lo] (x1) or [hi | lo | hi] (x2), and x2 hi transposed with zero padding.
+__global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                       const float* __restrict__ logit_scale, float scale_max, NceWs w,
+                                                       int B, int E) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float raw = __expf(logit_scale[0]);
+        const bool clamped = scale_max > 0.f && raw > scale_max;
+        w.scal[0] = clamped ? scale_max : raw;
+        w.scal[1] = clamped ? 1.f : 0.f;
+    }
+    const int64_t total = (int64_t)B * E;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / E;
+        const int c = (int)(i % E);
+        const float a = x1[i], t = x2[i];
+        const bf16_t ah = (bf16_t)a, th = (bf16_t)t;
+        const bf16_t al = (bf16_t)(a - (float)ah), tl = (bf16_t)(t - (float)th);
+        bf16_t* p1 = w.x1cat + r * 3 * E + c;
+        bf16_t* p2 = w.x2cat + r * 3 * E + c;
+        p1[0] = ah; p1[E] = ah; p1[2 * E] = al;
+        p2[0] = th; p2[E] = tl; p2[2 * E] = th;
+        w.x2t[(int64_t)c * w.Bp + r] = th;
+    }
+    const int pad = w.Bp - B;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)E * pad; i += (int64_t)gridDim.x * 256)
+        w.x2t[(i / pad) * w.Bp + B + (i % pad)] = (bf16_t)0.0f;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K, int row0, int nrows, float gscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ntm = (B + BM - 1) / BM, ntn = (B + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int tm = tile / ntn, tn = tile % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (PASS == 2) {
+        const bool rows_hit = m0 < row0 + nrows && m0 + BM > row0;
+        const bool cols_hit = n0 < row0 + nrows && n0 + BN > row0;
+        if (!rows_hit && !cols_hit) return;
+    }
+    f32x4 acc[8][4];
+    mainloop(smem, w.x1cat, K, B, w.x2cat, K, B, K, m0, n0, wave, lane, acc);
+    const float s = w.scal[0];
+    const int mb = m0 + wm * 128 + frow, nb = n0 + wn * 64 + fq * 4;
+
+    if (PASS == 1) {
+        // scale, mask, diagonal
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + i * 16, n = nb + j * 16 + r;
+                    const float z = (m < B && n < B) ? s * acc[i][j][r] : -INFINITY;
+                    acc[i][j][r] = z;
+                    if (m == n && m < B) w.diag[m] = z;
+                }
+        // rows: over this wave's 64 columns
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float ms = mx == -INFINITY ? 0.f : mx;
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = acc[i][j][r];
+                    const float e = __expf(z - ms);
+                    se += e;
+                    sw += z == -INFINITY ? 0.f : e * z;
+                }
+            se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+            sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
+            const int m = mb + i * 16;
+            if (fq == 0 && m < B) {
+                const int64_t o = (int64_t)(tn * 4 + wn) * B + m;
+                w.rmax[o] = mx; w.rsum[o] = se; w.rwz[o] = sw;
+            }
+        }
+        // columns: over this wave's 128 rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, acc[i][j][r]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                const float ms = mx == -INFINITY ? 0.f : mx;
+                float se = 0.f, sw = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = acc[i][j][r];
+                    const float e = __expf(z - ms);
+                    se += e;
+                    sw += z == -INFINITY ? 0.f : e * z;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { se += __shfl_xor(se, o, 64); sw += __shfl_xor(sw, o, 64); }
+                const int n = nb + j * 16 + r;
+                if (frow == 0 && n < B) {
+                    const int64_t o = (int64_t)(tm * 2 + wm) * B + n;
+                    w.cmax[o] = mx; w.csum[o] = se; w.cwz[o] = sw;
+                }
+            }
+    } else {
+        const float k = gscale / (float)B;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n4 = nb + j * 16;
+            if (n4 >= w.Bp) continue;
+            f32x4 cl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cl[r] = n4 + r < B ? w.clse[n4 + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + i * 16;
+                if (m >= B) continue;
+                const float rl = w.rlse[m];
+                f32x4 d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n4 + r;
+                    const float z = s * acc[i][j][r];
+                    const float g = (__expf(z - rl) + __expf(z - cl[r]) - (m == n ? 2.f : 0.f)) * k;
+                    d[r] = n < B ? g * s : 0.f;
+                }
+                *(bf16x4*)(w.dz + (int64_t)m * w.Bp + n4) = f32x4_to_bf16x4(d);
+            }
+        }
+    }
+}
+
+// Merge the per-tile triples; single workgroup (B <= 64k is tiny work).  loss = mean(rlse - d) + mean(clse - d);
+// dlogit_scale = gscale/B * (sum_i E_row[i] + sum_j E_col[j] - 2 sum_i d_i), zero when the scale is clamped.
+__global__ __launch_bounds__(1024) void nce_final_kernel(NceWs w, int B, float gscale, float* loss, float* dls) {
+    __shared__ float red[2][1024];
+    float lsum = 0.f, esum = 0.f;
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        float acc2[2][2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const float* pm = side == 0 ? w.rmax : w.cmax;
+            const float* ps = side == 0 ? w.rsum : w.csum;
+            const float* pw = side == 0 ? w.rwz : w.cwz;
+            const int parts = side == 0 ? w.rparts : w.cparts;
+            float mx = -INFINITY;
+            for (int p = 0; p < parts; ++p) mx = fmaxf(mx, pm[(int64_t)p * B + i]);
+            float se = 0.f, sw = 0.f;
+            for (int p = 0; p < parts; ++p) {
+                const float pmx = pm[(int64_t)p * B + i];
+                if (pmx == -INFINITY) continue;
+                const float f = __expf(pmx - mx);
+                se += ps[(int64_t)p * B + i] * f;
+                sw += pw[(int64_t)p * B + i] * f;
+            }
+            const float lse = mx + __logf(se);
+            (side == 0 ? w.rlse : w.clse)[i] = lse;
+            acc2[side][0] = lse;
+            acc2[side][1] = sw / se;
+        }
+        const float d = w.diag[i];
+        lsum += (acc2[0][0] - d) + (acc2[1][0] - d);
+        esum += acc2[0][1] + acc2[1][1] - 2.f * d;
+    }
+    red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = esum;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss[0] = red[0][0] / (float)B;
+        if (dls != nullptr) dls[0] = w.scal[1] != 0.f ? 0.f : red[1][0] * gscale / (float)B;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vipant_infonce_workspace_bytes(int64_t B, int64_t E) { return carve(nullptr, B, E).total; }
+
+extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, const float* logit_scale, float scale_max,
+                                          float* loss, float* dx1, float* dx2, float* dlogit_scale, float grad_scale,
+                                          int64_t B, int64_t E, int64_t row0, int64_t nrows, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(B > 0 && E > 0 && E % 64 == 0, VIPANT_EBADSHAPE, "infonce: need E %% 64 == 0 (B=%ld E=%ld)", (long)B, (long)E);
+    VIPANT_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= B && row0 % 8 == 0, VIPANT_EBADSHAPE,
+                   "infonce: bad row slice [%ld, %ld) of %ld (row0 must be a multiple of 8)", (long)row0, (long)(row0 + nrows), (long)B);
+    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_infonce_workspace_bytes(B, E), VIPANT_ENOWORKSPACE,
+                   "infonce: workspace too small");
+    VIPANT_REQUIRE((uintptr_t)workspace % 256 == 0, VIPANT_EALIGN, "infonce: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const NceWs w = carve((char*)workspace, B, E);
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        configured = true;
+    }
+    const int K = (int)(3 * E);
+    const unsigned tiles = (unsigned)(ceil_div(B, BM) * ceil_div(B, BN));
+    int64_t pb = ceil_div(B * E, 256);
+    hipLaunchKernelGGL(nce_prep_kernel, dim3((unsigned)(pb > 2048 ? 2048 : pb)), dim3(256), 0, s, x1, x2, logit_scale,
+                       scale_max, w, (int)B, (int)E);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_tile_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, 0, (int)B, 1.0f);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(1024), 0, s, w, (int)B, grad_scale, loss, dlogit_scale);
+    VIPANT_LAUNCH_CHECK();
+    if ((dx1 == nullptr && dx2 == nullptr) || nrows == 0) return VIPANT_OK;
+    hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)row0, (int)nrows, grad_scale);
+    VIPANT_LAUNCH_CHECK();
+    if (dx1 != nullptr) {
+        const int32_t e = vipant_gemm_nt((const uint16_t*)(w.dz + row0 * w.Bp), w.Bp, (const uint16_t*)w.x2t, w.Bp, dx1, E,
+                                         nullptr, nullptr, 1.0f, nrows, E, w.Bp, VIPANT_EPI_F32, stream);
+        if (e != VIPANT_OK) return e;
+    }
+    if (dx2 != nullptr) {
+        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + row0), w.Bp, (const uint16_t*)w.x1cat, 3 * E, dx2, E, B,
+                                         nrows, E, 0, w.tn_ws, w.tn_bytes, stream);
+        if (e != VIPANT_OK) return e;
+    }
+    return VIPANT_OK;
+}

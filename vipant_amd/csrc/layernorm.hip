@@ -1,0 +1,194 @@
+// LayerNorm forward / backward with fp32 statistics (clip/model.py:154-160, eps = 1e-5).
+// HBM-bound: one wave per token row, 16-byte accesses, wave-shuffle reductions, fp32 in / bf16 out so
+// that the normalised activations feed the next MFMA contraction without another cast pass.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+template <int NV>  // D = NV * 256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ y32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t M) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    f32x4 gv[NV], bv[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        gv[t] = *(const f32x4*)(gamma + (t * 64 + lane) * 4);
+        bv[t] = *(const f32x4*)(beta + (t * 64 + lane) * 4);
+    }
+    for (int64_t row = wave; row < M; row += nwaves) {
+        const float* xr = x + row * ldx;
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            v[t] = *(const f32x4*)(xr + (t * 64 + lane) * 4);
+            s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
+        }
+        const float mu = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            v[t] -= mu;
+            q += v[t][0] * v[t][0] + v[t][1] * v[t][1] + v[t][2] * v[t][2] + v[t][3] * v[t][3];
+        }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const f32x4 o = v[t] * rs * gv[t] + bv[t];
+            const int64_t off = row * D + (t * 64 + lane) * 4;
+            if (y != nullptr) *(bf16x4*)(y + off) = f32x4_to_bf16x4(o);
+            if (y32 != nullptr) *(f32x4*)(y32 + off) = o;
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
+// Per-block partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to `partial` [grid, 2, D].
+template <int NV, bool DY_F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+                                                     int64_t ldx, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* dres, float* dx, int64_t lddx,
+                                                     bf16_t* __restrict__ dxb, float* __restrict__ partial, int64_t M) {
+    constexpr int D = NV * 256;
+    __shared__ float red[4 * 2 * D > 0 ? 4 * 2 * D : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    f32x4 gv[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        gv[t] = *(const f32x4*)(gamma + (t * 64 + lane) * 4);
+        dg[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = wave; row < M; row += nwaves) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int col = (t * 64 + lane) * 4;
+            f32x4 dyv;
+            if (DY_F32) {
+                dyv = *(const f32x4*)((const float*)dy_ + row * D + col);
+            } else {
+                const bf16x4 b = *(const bf16x4*)((const bf16_t*)dy_ + row * D + col);
+                dyv = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+            xh[t] = (*(const f32x4*)(x + row * ldx + col) - mu) * rs;
+            g[t] = dyv * gv[t];
+            dg[t] += dyv * xh[t];
+            db[t] += dyv;
+            s1 += g[t][0] + g[t][1] + g[t][2] + g[t][3];
+            s2 += g[t][0] * xh[t][0] + g[t][1] * xh[t][1] + g[t][2] * xh[t][2] + g[t][3] * xh[t][3];
+        }
+        s1 = wave_sum(s1) * (1.0f / D);
+        s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int col = (t * 64 + lane) * 4;
+            f32x4 o = (g[t] - s1 - xh[t] * s2) * rs;
+            if (dres != nullptr) o += *(const f32x4*)(dres + row * lddx + col);
+            if (dx != nullptr) *(f32x4*)(dx + row * lddx + col) = o;
+            if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
+        }
+    }
+    // block reduction of the 4 waves' partial column sums, then one row of partials per block
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        *(f32x4*)(red + (wv * 2 + 0) * D + (t * 64 + lane) * 4) = dg[t];
+        *(f32x4*)(red + (wv * 2 + 1) * D + (t * 64 + lane) * 4) = db[t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256)
+        partial[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+}
+
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D, float* dgamma,
+                                       float* dbeta, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * D) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * D + i];
+    float* dst = i < D ? dgamma + i : dbeta + (i - D);
+    *dst = accumulate ? *dst + s : s;
+}
+
+int ln_blocks(int64_t M) {
+    int64_t b = ceil_div(M, 4);
+    return (int)(b > 1024 ? 1024 : b);
+}
+
+}  // namespace
+
+extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                        uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
+                                        void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
+                   "layernorm_fwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
+    VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)(ceil_div(M, 4) > 2048 ? 2048 : ceil_div(M, 4));
+#define LN_FWD(NV)                                                                                                   \
+    hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, y_f32, mean, \
+                       rstd, M)
+    switch (D / 256) {
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 3: LN_FWD(3); break;
+        default: LN_FWD(4); break;
+    }
+#undef LN_FWD
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
+    return (size_t)ln_blocks(M) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx,
+                                        const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                        float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
+                                        int32_t accumulate, int64_t M, int64_t D, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
+                   "layernorm_bwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
+    VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && lddx >= D && lddx % 4 == 0, VIPANT_EALIGN, "layernorm_bwd: bad strides");
+    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_layernorm_bwd_workspace_bytes(M, D),
+                   VIPANT_ENOWORKSPACE, "layernorm_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = ln_blocks(M);
+    float* partial = (float*)workspace;
+#define LN_BWD(NV)                                                                                                   \
+    do {                                                                                                             \
+        if (dy_is_f32)                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd,     \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd,    \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+    } while (0)
+    switch (D / 256) {
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        case 3: LN_BWD(3); break;
+        default: LN_BWD(4); break;
+    }
+#undef LN_BWD
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(2 * D, 256)), dim3(256), 0, s,
+                       (const float*)partial, blocks, (int)D, dgamma, dbeta, accumulate);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}

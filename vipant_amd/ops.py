@@ -1,0 +1,516 @@
+"""Tensor-level wrappers over the C ABI plus the autograd nodes of the contrastive step.
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape; every numeric
+operation below is a call into libvipant_hip.so (hand-written gfx950 kernels).  Nothing in this file
+computes on the CPU or through ATen kernels, except zero-fills / views used as allocation helpers.
+
+Activation layout: token-major [M, D] with M = batch * tokens, row m = b * S + s (batch-first).
+The residual stream and its gradient are fp32; every MFMA operand is bf16 (fp32 accumulate).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _ffi
+from ._ffi import (EPI_BF16, EPI_DQUICKGELU, EPI_F32, EPI_QUICKGELU, EPI_RESIDUAL_F32, EPI_SCALE_F32,  # noqa: F401
+                   call, query)
+
+BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+
+# order of the 12 per-layer parameters handed to BackboneFn (reference names, cvap/module/val.py:496-507)
+BLOCK_PARAM_NAMES = (
+    "ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias",
+    "attn.out_proj.weight", "attn.out_proj.bias", "ln_2.weight", "ln_2.bias",
+    "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias",
+)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _ffi.VipantError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _ffi.VipantError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1 and t.numel() > 1:
+        raise _ffi.VipantError(f"{name}: last dimension must be contiguous")
+
+
+_scratch: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def scratch(name: str, nbytes: int, device) -> torch.Tensor:
+    """Named, grow-only byte workspace (256-B aligned by the caching allocator)."""
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------- raw ops
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux=None, epi: int = EPI_BF16,
+            alpha: float = 1.0):
+    """c[M,N] = a[M,K] @ b[N,K]^T with the epilogue `epi` (see include/vipant_hip.h)."""
+    _need(a, BF16, "gemm_nt.a"); _need(b, BF16, "gemm_nt.b")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
+    if aux is not None:
+        assert aux.stride(0) == c.stride(0)
+    call("vipant_gemm_nt", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+         _ptr(bias), _ptr(aux), float(alpha), M, N, K, epi, _stream())
+    return c
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
+    """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out)."""
+    _need(a, BF16, "gemm_tn.a"); _need(b, BF16, "gemm_tn.b"); _need(c, F32, "gemm_tn.c")
+    M, P = a.shape
+    Q = b.shape[1]
+    assert b.shape[0] == M and tuple(c.shape) == (P, Q), (a.shape, b.shape, c.shape)
+    nbytes = query("vipant_gemm_tn_workspace_bytes", M, P, Q)
+    ws = scratch("gemm_tn", nbytes, a.device)
+    call("vipant_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), M, P, Q,
+         int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return c
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+    _need(x, BF16, "colsum.x"); _need(out, F32, "colsum.out")
+    M, N = x.shape
+    ws = scratch("colsum", query("vipant_colsum_workspace_bytes", M, N), x.device)
+    call("vipant_colsum_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), M, N, int(accumulate), ws.data_ptr(),
+         ws.numel(), _stream())
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma, beta, *, want_bf16=True, want_f32=False, rows: Optional[int] = None,
+                  ldx: Optional[int] = None):
+    """x fp32 [M, D] (or `rows` rows with stride `ldx`) -> (y_bf16 | None, y_f32 | None, mean, rstd)."""
+    _need(x, F32, "layernorm_fwd.x")
+    D = x.shape[-1]
+    M = rows if rows is not None else x.shape[0]
+    ldx = ldx if ldx is not None else x.stride(0)
+    y = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    y32 = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    call("vipant_layernorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32),
+         mean.data_ptr(), rstd.data_ptr(), M, D, _stream())
+    return y, y32, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=None, dx=None, lddx=None,
+                  dx_bf16=None, dgamma, dbeta, accumulate=False, rows=None, ldx=None):
+    D = x.shape[-1]
+    M = rows if rows is not None else x.shape[0]
+    ldx = ldx if ldx is not None else x.stride(0)
+    lddx = lddx if lddx is not None else (dx.stride(0) if dx is not None else D)
+    ws = scratch("ln_bwd", query("vipant_layernorm_bwd_workspace_bytes", M, D), x.device)
+    call("vipant_layernorm_bwd", dy.data_ptr(), int(dy.dtype == F32), x.data_ptr(), ldx, mean.data_ptr(),
+         rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), _ptr(dx), lddx, _ptr(dx_bf16), dgamma.data_ptr(),
+         dbeta.data_ptr(), int(accumulate), M, D, ws.data_ptr(), ws.numel(), _stream())
+
+
+def mha_fwd(qkv: torch.Tensor, batch: int, S: int, H: int, causal: bool):
+    _need(qkv, BF16, "mha_fwd.qkv")
+    out = torch.empty((batch * S, H * 64), dtype=BF16, device=qkv.device)
+    lse = torch.empty((batch, H, S), dtype=F32, device=qkv.device)
+    call("vipant_mha_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, S, H, int(causal), _stream())
+    return out, lse
+
+
+def mha_bwd(qkv, out, dout, lse, batch: int, S: int, H: int, causal: bool):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    call("vipant_mha_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+         dqkv.data_ptr(), batch, S, H, int(causal), _stream())
+    return dqkv
+
+
+def cast_bf16(w: torch.Tensor, transpose: bool = False):
+    """fp32 matrix -> (bf16 copy, bf16 transposed copy | None)."""
+    _need(w, F32, "cast_bf16.w")
+    w2 = w.reshape(w.shape[0], -1) if w.dim() != 2 else w
+    assert w2.is_contiguous()
+    R, Cc = w2.shape
+    dst = torch.empty((R, Cc), dtype=BF16, device=w.device)
+    dst_t = torch.empty((Cc, R), dtype=BF16, device=w.device) if transpose else None
+    call("vipant_cast_bf16", w2.data_ptr(), dst.data_ptr(), _ptr(dst_t), R, Cc, _stream())
+    return dst, dst_t
+
+
+def cast_bf16_flat(x: torch.Tensor) -> torch.Tensor:
+    _need(x, F32, "cast_bf16_flat.x")
+    assert x.is_contiguous() and x.numel() % 4 == 0
+    dst = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("vipant_cast_bf16", x.data_ptr(), dst.data_ptr(), None, 1, x.numel(), _stream())
+    return dst
+
+
+_frozen_cache: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
+
+
+def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
+    """bf16 copy of a frozen weight, cached until the tensor is modified (frozen towers, eval)."""
+    key = (w.data_ptr(), w._version, transpose_only)
+    hit = _frozen_cache.get(key)
+    if hit is None:
+        if len(_frozen_cache) > 4096:
+            _frozen_cache.clear()
+        hit = cast_bf16(w.detach(), transpose=transpose_only)
+        _frozen_cache[key] = hit
+    return hit[1] if transpose_only else hit[0]
+
+
+# ---------------------------------------------------------------------------------- patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + MFMA contraction, cls token,
+    positional table, ln_pre.  x fp32 [b, C, T, F] -> residual stream fp32 [b*S, D]."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, cls, pos, ln_w, ln_b, stride):
+        _need(x, F32, "patch_embed.x")
+        x = x.contiguous()
+        b, Cx, T, Fq = x.shape
+        D, Cw, ph, pw = conv_w.shape
+        sh, sw = int(stride[0]), int(stride[1])
+        nrow, ncol = (T - ph) // sh + 1, (Fq - pw) // sw + 1
+        P, S = nrow * ncol, nrow * ncol + 1
+        assert pos.shape[0] >= S, f"positional table has {pos.shape[0]} rows, need {S}"
+        # cvap/module/val.py:236-244: non-RGB input with a multi-channel kernel -> channel-mean kernel
+        mean_ch = Cx != 3 and Cx != Cw
+        assert mean_ch or Cx == Cw, f"input has {Cx} channels, kernel {Cw}"
+        kcols = (1 if mean_ch else Cw) * ph * pw
+        dev = x.device
+        w_eff = torch.empty((D, kcols), dtype=BF16, device=dev)
+        call("vipant_conv_weight_prep", conv_w.detach().contiguous().data_ptr(), w_eff.data_ptr(), D, Cw, ph * pw,
+             int(mean_ch), _stream())
+        patches = torch.empty((b * P, kcols), dtype=BF16, device=dev)
+        call("vipant_im2col", x.data_ptr(), patches.data_ptr(), b, Cx, T, Fq, ph, pw, sh, sw, _stream())
+        pe = torch.empty((b * P, D), dtype=F32, device=dev)
+        gemm_nt(patches, w_eff, pe, epi=EPI_F32)
+        tok = torch.empty((b * S, D), dtype=F32, device=dev)
+        call("vipant_assemble_tokens", pe.data_ptr(), cls.detach().contiguous().data_ptr(),
+             pos.detach().contiguous().data_ptr(), tok.data_ptr(), b, P, D, _stream())
+        _, out, mean, rstd = layernorm_fwd(tok, ln_w.detach(), ln_b.detach(), want_bf16=False, want_f32=True)
+        ctx.save_for_backward(patches, tok, mean, rstd, ln_w)
+        ctx.meta = (b, P, D, Cw, ph * pw, mean_ch, tuple(conv_w.shape), tuple(pos.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        patches, tok, mean, rstd, ln_w = ctx.saved_tensors
+        b, P, D, Cw, khw, mean_ch, conv_shape, pos_shape = ctx.meta
+        dev = dout.device
+        dout = dout.contiguous()
+        dtok = torch.empty_like(tok)
+        dlnw = torch.empty((D,), dtype=F32, device=dev)
+        dlnb = torch.empty((D,), dtype=F32, device=dev)
+        layernorm_bwd(dout, tok, mean, rstd, ln_w.detach(), dx=dtok, dgamma=dlnw, dbeta=dlnb)
+        dpatch = torch.empty((b * P, D), dtype=BF16, device=dev)
+        dcls = torch.empty((D,), dtype=F32, device=dev)
+        dpos = torch.zeros(pos_shape, dtype=F32, device=dev)
+        call("vipant_assemble_tokens_bwd", dtok.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), 0, b, P,
+             D, _stream())
+        dw_eff = torch.empty((D, patches.shape[1]), dtype=F32, device=dev)
+        gemm_tn(dpatch, patches, dw_eff)
+        if mean_ch:
+            dconv = torch.empty(conv_shape, dtype=F32, device=dev)
+            call("vipant_conv_weight_grad", dw_eff.data_ptr(), dconv.data_ptr(), D, Cw, khw, 0, _stream())
+        else:
+            dconv = dw_eff.view(conv_shape)
+        return None, dconv, dcls, dpos, dlnw, dlnb, None
+
+
+# ---------------------------------------------------------------------------------- transformer
+class _LayerGrads:
+    """fp32 gradients of one block, carved from one flat buffer so a replica group can all-reduce a whole
+    layer with a single RCCL call as soon as its backward is done."""
+
+    def __init__(self, shapes: Sequence[torch.Size], device):
+        sizes = [int(torch.Size(s).numel()) for s in shapes]
+        pad = [(n + 3) // 4 * 4 for n in sizes]            # keep every view 16-byte aligned
+        self.flat = torch.empty((sum(pad),), dtype=F32, device=device)
+        self.views, off = [], 0
+        for s, n, p in zip(shapes, sizes, pad):
+            self.views.append(self.flat[off:off + n].view(s))
+            off += p
+
+
+class BackboneFn(torch.autograd.Function):
+    """TransformerBackbone.forward = L x ResidualAttentionBlock (cvap/module/val.py:493-522) on the fp32
+    residual stream x [batch*S, D].  One autograd node for the whole stack: the layer loop, the saved
+    activations and the (fp32, bf16) gradient-stream pair between layers are managed here, not by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, batch, S, causal, grad_sync, *params):
+        _need(x, F32, "backbone.x")
+        M, D = x.shape
+        assert M == batch * S and len(params) % 12 == 0
+        L, H = len(params) // 12, D // 64
+        train = any(ctx.needs_input_grad)
+        dev = x.device
+        saved: List[torch.Tensor] = []
+        wts: List[Tuple[torch.Tensor, ...]] = []
+        x = x.contiguous()
+        if not train:   # frozen tower: one pair of residual buffers and one set of temporaries for all layers
+            qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+            u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            xa, xb = torch.empty_like(x), torch.empty_like(x)
+        for l in range(L):
+            ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
+            if train:
+                wqkv_b, wqkv_t = cast_bf16(wqkv, True); wo_b, wo_t = cast_bf16(wo, True)
+                wfc_b, wfc_t = cast_bf16(wfc, True); wpr_b, wpr_t = cast_bf16(wpr, True)
+                wts.append((wqkv_t, wo_t, wfc_t, wpr_t))
+                qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+                u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+                g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+                x1, x2 = torch.empty_like(x), torch.empty_like(x)
+            else:
+                wqkv_b, wo_b, wfc_b, wpr_b = (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
+                x1, x2 = xa, xb
+            h1, _, mean1, rstd1 = layernorm_fwd(x, ln1w, ln1b)
+            gemm_nt(h1, wqkv_b, qkv, bias=bqkv, epi=EPI_BF16)
+            o, lse = mha_fwd(qkv, batch, S, H, causal)
+            gemm_nt(o, wo_b, x1, bias=bo, aux=x, epi=EPI_RESIDUAL_F32)
+            h2, _, mean2, rstd2 = layernorm_fwd(x1, ln2w, ln2b)
+            gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
+            gemm_nt(g, wpr_b, x2, bias=bpr, aux=x1, epi=EPI_RESIDUAL_F32)
+            if train:
+                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g]
+            x = x2
+        if train:
+            ctx.save_for_backward(*saved, *params)
+            ctx.wts = wts
+            ctx.meta = (batch, S, bool(causal), L, H)
+            ctx.grad_sync = grad_sync
+        return x
+
+    @staticmethod
+    def backward(ctx, dx_in):
+        batch, S, causal, L, H = ctx.meta
+        tensors = ctx.saved_tensors
+        saved, params = tensors[:13 * L], tensors[13 * L:]
+        dev = dx_in.device
+        dx = dx_in.contiguous()
+        M, D = dx.shape
+        dx_b = cast_bf16_flat(dx)
+        grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
+        for l in reversed(range(L)):
+            x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g = saved[13 * l:13 * l + 13]
+            ln1w, _, _, _, _, _, ln2w, _, _, _, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
+            wqkv_t, wo_t, wfc_t, wpr_t = ctx.wts[l]
+            lg = _LayerGrads([p.shape for p in params[12 * l:12 * l + 12]], dev)
+            (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
+            # c_proj + QuickGELU'
+            du = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            gemm_nt(dx_b, wpr_t, du, aux=u, epi=EPI_DQUICKGELU)
+            gemm_tn(dx_b, g, d_wpr)
+            colsum(dx_b, d_bpr)
+            # c_fc
+            dh2 = torch.empty((M, D), dtype=BF16, device=dev)
+            gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
+            gemm_tn(du, h2, d_wfc)
+            colsum(du, d_bfc)
+            del du
+            # ln_2 (+ residual gradient)
+            dx1 = torch.empty((M, D), dtype=F32, device=dev)
+            dx1_b = torch.empty((M, D), dtype=BF16, device=dev)
+            layernorm_bwd(dh2, x1, mean2, rstd2, ln2w, dres=dx, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln2w, dbeta=d_ln2b)
+            # out_proj
+            do = dh2
+            gemm_nt(dx1_b, wo_t, do, epi=EPI_BF16)
+            gemm_tn(dx1_b, o, d_wo)
+            colsum(dx1_b, d_bo)
+            # attention core
+            dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
+            # in_proj
+            dh1 = do
+            gemm_nt(dqkv, wqkv_t, dh1, epi=EPI_BF16)
+            gemm_tn(dqkv, h1, d_wqkv)
+            colsum(dqkv, d_bqkv)
+            del dqkv
+            # ln_1 (+ residual gradient); reuse the stream buffers in place
+            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln1w, dbeta=d_ln1b)
+            dx, dx_b = dx1, dx1_b
+            for i, v in enumerate(lg.views):
+                grads[12 * l + i] = v
+            if ctx.grad_sync is not None:
+                ctx.grad_sync.reduce_async(lg.flat)
+        ctx.wts = None
+        need = ctx.needs_input_grad
+        out_grads = [gr if need[5 + i] else None for i, gr in enumerate(grads)]
+        return (dx if need[0] else None, None, None, None, None, *out_grads)
+
+
+# ---------------------------------------------------------------------------------- read-out
+class ReadoutFn(torch.autograd.Function):
+    """ViTPostEncoder / GPTPostEncoder (cvap/module/val.py:288-289, 143-145) + the optional L2 normalisation of
+    MetaHead.forward (clip_head.py:117-118): LN(x[b, idx_b]) @ proj -> [batch, E] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, idx, batch, S, ln_w, ln_b, proj, normalized):
+        _need(x, F32, "readout.x")
+        x = x.contiguous()
+        D, E = proj.shape
+        dev = x.device
+        train = any(ctx.needs_input_grad)
+        if idx is None:
+            rows, src, ld = batch, x, S * D                # cls row of every sample: strided view, no copy
+        else:
+            src = torch.empty((batch, D), dtype=F32, device=dev)
+            call("vipant_gather_rows", x.data_ptr(), idx.data_ptr(), src.data_ptr(), batch, S, D, _stream())
+            rows, ld = batch, D
+        y, _, mean, rstd = layernorm_fwd(src, ln_w.detach(), ln_b.detach(), rows=rows, ldx=ld)
+        if train:
+            proj_b, proj_t = cast_bf16(proj.detach(), True)
+        else:
+            proj_b, proj_t = None, cached_bf16(proj, transpose_only=True)
+        feat = torch.empty((batch, E), dtype=F32, device=dev)
+        gemm_nt(y, proj_t, feat, epi=EPI_F32)
+        norm = None
+        if normalized:
+            out = torch.empty_like(feat)
+            norm = torch.empty((batch,), dtype=F32, device=dev)
+            call("vipant_l2norm_fwd", feat.data_ptr(), out.data_ptr(), norm.data_ptr(), batch, E, _stream())
+        else:
+            out = feat
+        if train:
+            ctx.save_for_backward(x, idx, src if idx is not None else None, y, mean, rstd, ln_w, proj_b, out, norm)
+            ctx.meta = (batch, S, D, E, bool(normalized))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, idx, src, y, mean, rstd, ln_w, proj_b, out, norm = ctx.saved_tensors
+        batch, S, D, E, normalized = ctx.meta
+        dev = dout.device
+        dout = dout.contiguous()
+        df_b = torch.empty((batch, E), dtype=BF16, device=dev)
+        if normalized:
+            call("vipant_l2norm_bwd", dout.data_ptr(), out.data_ptr(), norm.data_ptr(), None, df_b.data_ptr(), batch, E,
+                 _stream())
+        else:
+            df_b = cast_bf16_flat(dout)
+        dy = torch.empty((batch, D), dtype=BF16, device=dev)
+        gemm_nt(df_b, proj_b, dy, epi=EPI_BF16)               # dy = dfeat @ proj^T ; proj [D, E] is the [N, K] operand
+        dproj = torch.empty((D, E), dtype=F32, device=dev)
+        gemm_tn(y, df_b, dproj)
+        dlnw = torch.empty((D,), dtype=F32, device=dev)
+        dlnb = torch.empty((D,), dtype=F32, device=dev)
+        dx = torch.zeros_like(x)
+        if idx is None:
+            layernorm_bwd(dy, x, mean, rstd, ln_w.detach(), dx=dx, lddx=S * D, dgamma=dlnw, dbeta=dlnb, rows=batch,
+                          ldx=S * D)
+        else:
+            dsrc = torch.empty((batch, D), dtype=F32, device=dev)
+            layernorm_bwd(dy, src, mean, rstd, ln_w.detach(), dx=dsrc, dgamma=dlnw, dbeta=dlnb)
+            call("vipant_scatter_rows", dsrc.data_ptr(), idx.data_ptr(), dx.data_ptr(), batch, S, D, _stream())
+        return dx, None, None, None, dlnw, dlnb, dproj, None
+
+
+def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor):
+    """GPTPreEncoder.forward (cvap/module/val.py:109-122): returns (x fp32 [b*L, D], eot index i64 [b])."""
+    _need(tokens, I64, "embed_tokens.tokens")
+    tokens = tokens.contiguous()
+    b, L = tokens.shape
+    D = table.shape[1]
+    assert pos.shape[0] >= L
+    x = torch.empty((b * L, D), dtype=F32, device=tokens.device)
+    eot = torch.empty((b,), dtype=I64, device=tokens.device)
+    call("vipant_embed_tokens", tokens.data_ptr(), table.detach().data_ptr(), pos.detach().contiguous().data_ptr(),
+         x.data_ptr(), eot.data_ptr(), b, L, D, _stream())
+    return x, eot
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """x / ||x|| for pre-computed features (cvap/model/cvalp.py:45-46); no gradient path (inputs are data)."""
+    _need(x, F32, "l2_normalize.x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    norm = torch.empty((x.shape[0],), dtype=F32, device=x.device)
+    call("vipant_l2norm_fwd", x.data_ptr(), out.data_ptr(), norm.data_ptr(), x.shape[0], x.shape[1], _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------- InfoNCE
+class InfoNCEFn(torch.autograd.Function):
+    """CELossHead.forward (cvap/module/decoder/loss_head.py:265-284) on L2-normalised fp32 features.
+
+    x1, x2: [B, E] -- the (all-gathered) global batch.  Gradients are produced only for rows
+    [row0, row0 + nrows): the slice this replica owns; other rows get zero (their owners compute them).
+    `grad_scale` pre-multiplies the slice gradients (replicas whose parameter gradients are averaged set it
+    to the world size so that the mean over ranks equals the full-batch gradient)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, logit_scale, scale_max, row0, nrows, grad_scale):
+        _need(x1, F32, "infonce.x1"); _need(x2, F32, "infonce.x2")
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, E = x1.shape
+        dev = x1.device
+        need = ctx.needs_input_grad
+        want = need[0] or need[1] or need[2]
+        ws = scratch("infonce", query("vipant_infonce_workspace_bytes", B, E), dev)
+        loss = torch.empty((1,), dtype=F32, device=dev)
+        d1 = torch.empty((nrows, E), dtype=F32, device=dev) if want else None
+        d2 = torch.empty((nrows, E), dtype=F32, device=dev) if want else None
+        dls = torch.empty((1,), dtype=F32, device=dev) if want else None
+        ls = logit_scale.detach().reshape(1).to(F32)
+        call("vipant_infonce_fwd_bwd", x1.data_ptr(), x2.data_ptr(), ls.data_ptr(), float(scale_max or 0.0),
+             loss.data_ptr(), _ptr(d1), _ptr(d2), _ptr(dls), float(grad_scale), B, E, int(row0), int(nrows),
+             ws.data_ptr(), ws.numel(), _stream())
+        if want:
+            ctx.save_for_backward(d1, d2, dls)
+            ctx.meta = (B, E, int(row0), int(nrows), tuple(logit_scale.shape))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        d1, d2, dls = ctx.saved_tensors
+        B, E, row0, nrows, ls_shape = ctx.meta
+        need = ctx.needs_input_grad
+
+        def expand(d):
+            full = torch.zeros((B, E), dtype=F32, device=d.device)
+            full[row0:row0 + nrows] = d * dloss
+            return full
+        return (expand(d1) if need[0] else None, expand(d2) if need[1] else None,
+                (dls * dloss).reshape(ls_shape) if need[2] else None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------- LARS
+class LarsState:
+    """Device-side pointer tables for vipant_lars_step (cvap/module/lars.py:43-72); built once per optimizer."""
+
+    def __init__(self, params: Sequence[torch.Tensor], adapt: Sequence[bool]):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.mu = [torch.zeros_like(p) for p in self.params]
+        self.n = torch.tensor([p.numel() for p in self.params], dtype=I64, device=dev)
+        self.adapt = torch.tensor([int(a) for a in adapt], dtype=torch.int32, device=dev)
+        self.p_ptrs = torch.tensor([p.data_ptr() for p in self.params], dtype=I64, device=dev)
+        self.mu_ptrs = torch.tensor([m.data_ptr() for m in self.mu], dtype=I64, device=dev)
+        self.ws = torch.empty((query("vipant_lars_workspace_bytes", len(self.params)),), dtype=torch.uint8, device=dev)
+
+    def step(self, grads: Sequence[torch.Tensor], lrs: Sequence[float], weight_decay: float, momentum: float, eta: float):
+        dev = self.params[0].device
+        for p, g in zip(self.params, grads):
+            assert g.is_contiguous() and g.dtype == F32 and g.shape == p.shape
+        g_ptrs = torch.tensor([g.data_ptr() for g in grads], dtype=I64, device=dev)
+        lr = torch.tensor(list(lrs), dtype=F32, device=dev)
+        call("vipant_lars_step", self.p_ptrs.data_ptr(), g_ptrs.data_ptr(), self.mu_ptrs.data_ptr(), self.n.data_ptr(),
+             self.adapt.data_ptr(), lr.data_ptr(), len(self.params), float(weight_decay), float(momentum), float(eta),
+             self.ws.data_ptr(), self.ws.numel(), _stream())
