@@ -1,0 +1,222 @@
+"""Module-level parity on the MI355X against golden vectors produced by the imported reference
+(tests/golden/make_golden.py): transformer block, pre / post encoders, frozen text and image towers, and the
+end-to-end VA step (features, loss, gradients).
+
+Tolerances.  The HIP path feeds bf16 operands to MFMA (fp32 accumulate, fp32 residual stream); the golden vectors
+are the reference's fp32 CPU path.  bf16 rounding (2^-9 relative per operand) gives ~0.3-1 % error on a single
+contraction output and a few % on gradients that pass through 12 layers; each check below states its budget
+relative to the tensor's own scale (max |ref|), never absolute-only.
+"""
+import math
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gen  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def M():
+    import vipant_amd.module as mod
+    from vipant_amd import _ffi
+    _ffi.call("vipant_device_check")
+    return mod
+
+
+def rel_err(got, ref):
+    got, ref = torch.as_tensor(got).double().cpu(), torch.as_tensor(ref).double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(got, ref):
+    got, ref = torch.as_tensor(got).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def audio_cfg(T, Fq, layers, name="CLIPAudioHead"):
+    return NS(name=name, width=768, embed_dim=512, resolution=[T, Fq], ctx_len=77,
+              encoder=NS(name="TransformerBackbone", layers=layers, skip_attn_mask=True),
+              pre_encoder=NS(name="ViTPreEncoder", patch_size=32, stride=[16, 24], in_channels=3),
+              post_encoder=NS(name="ViTPostEncoder"), misc=NS(name="CLIPMisc"),
+              pre_encoder_addon=NS(name="AddonEncoder"), post_encoder_addon=NS(name="AddonEncoder"))
+
+
+def image_cfg(layers):
+    return NS(name="CLIPImageHead", width=768, embed_dim=512, resolution=224, ctx_len=77,
+              encoder=NS(name="TransformerBackbone", layers=layers, skip_attn_mask=True),
+              pre_encoder=NS(name="ViTPreEncoder", patch_size=32, stride=32, in_channels=3),
+              post_encoder=NS(name="ViTPostEncoder"), misc=NS(name="CLIPMisc"),
+              pre_encoder_addon=NS(name="AddonEncoder"), post_encoder_addon=NS(name="AddonEncoder"))
+
+
+def text_cfg(layers):
+    return NS(name="CLIPTextHead", width=512, embed_dim=512, resolution=None, ctx_len=77,
+              encoder=NS(name="TransformerBackbone", layers=layers, skip_attn_mask=False),
+              pre_encoder=NS(name="GPTPreEncoder", vocab_size=49408),
+              post_encoder=NS(name="GPTPostEncoder"), misc=NS(name="CLIPMisc"),
+              pre_encoder_addon=NS(name="AddonEncoder"), post_encoder_addon=NS(name="AddonEncoder"))
+
+
+@pytest.mark.parametrize("tag,D,S,b,causal", [("vit_s31", 768, 31, 2, False), ("vit_s316", 768, 316, 1, False),
+                                                ("gpt_s77", 512, 77, 2, True)])
+def test_block_golden(M, golden, tag, D, S, b, causal):
+    g = golden(f"block_{tag}")
+    bb = M.TransformerBackbone(NS(layers=1, skip_attn_mask=not causal), width=D, ctx_len=77 if causal else None)
+    w = gen.det_weights(f"block/{tag}", gen.backbone_shapes(D, 1))
+    bb.load_state_dict({k[len("encoder."):]: v for k, v in w.items()}, strict=True)
+    bb = bb.to(DEV)
+    x = gen.det_randn(f"block/{tag}/x", (b, S, D)).to(DEV).requires_grad_()
+    y = bb(x)
+    assert rel_err(y, g["y"]) < 1.5e-2, rel_err(y, g["y"])                 # one block, bf16 operands
+    y.backward(gen.det_randn(f"block/{tag}/gy", (b, S, D)).to(DEV))
+    assert rel_err(x.grad, g["dx"]) < 3e-2, rel_err(x.grad, g["dx"])
+    for k, p in bb.named_parameters():
+        ref_norm = float(g[f"n_{k}"])
+        assert abs(float(p.grad.norm()) / ref_norm - 1) < 2e-2, (k, float(p.grad.norm()), ref_norm)
+        if f"g_{k}" in g.files:
+            assert rel_err(p.grad, g[f"g_{k}"]) < 4e-2, (k, rel_err(p.grad, g[f"g_{k}"]))
+    sl = dict(bb.named_parameters())
+    assert rel_err(sl["resblocks.0.attn.in_proj_weight"].grad[::97, ::13], g["g_in_proj_w_rows"]) < 4e-2
+    assert rel_err(sl["resblocks.0.mlp.c_fc.weight"].grad[::131, ::17], g["g_c_fc_w_rows"]) < 4e-2
+
+
+@pytest.mark.parametrize("tag,T,Fq,b", [("256x64", 256, 64, 3), ("1024x128", 1024, 128, 2)])
+def test_pre_post_golden(M, golden, tag, T, Fq, b):
+    g = golden(f"prepost_{tag}")
+    head = M.build_audio_head(audio_cfg(T, Fq, 1))
+    S = head.misc.positional_embedding.shape[0]
+    assert S == int(g["S"]) and tuple(head.misc.position_resolution) == tuple(g["position_resolution"])
+    head.load_state_dict(gen.det_weights(f"prepost/{tag}", gen.vit_head_shapes(768, 1, 512, S)), strict=True)
+    head = head.to(DEV)
+    x = gen.det_randn(f"prepost/{tag}/x", (b, 1, T, Fq)).to(DEV)
+    pre = head.pre_encoder(x, positional_embedding=head.misc.pos_embedding, class_embedding=head.misc.cls_embedding)
+    assert rel_err(pre, g["pre"]) < 1e-2, rel_err(pre, g["pre"])
+    pre.backward(gen.det_randn(f"prepost/{tag}/gpre", tuple(pre.shape)).to(DEV))
+    assert rel_err(head.misc.positional_embedding.grad[::5], g["g_pos"]) < 1e-3       # fp32 LN / reduction path
+    assert rel_err(head.misc.class_embedding.grad, g["g_cls"]) < 1e-3
+    assert rel_err(head.pre_encoder.ln.weight.grad, g["g_ln_w"]) < 1e-2
+    assert rel_err(head.pre_encoder.ln.bias.grad, g["g_ln_b"]) < 1e-3
+    gc = head.pre_encoder.conv1.weight.grad
+    assert abs(float(gc.norm()) / float(g["g_conv_norm"]) - 1) < 1e-2
+    assert rel_err(gc[::61, :, ::5, ::7], g["g_conv_slice"]) < 2e-2
+    h = gen.det_randn(f"prepost/{tag}/h", (b, S, 768)).to(DEV)
+    post = head.post_encoder(h)
+    assert rel_err(post, g["post"]) < 1e-2, rel_err(post, g["post"])
+
+
+def test_text_head_golden(M, golden):
+    g = golden("text_l2")
+    head = M.build_text_head(text_cfg(2))
+    w = gen.det_weights("text/l2", gen.text_head_shapes(512, 2, 512))
+    assert sorted(head.state_dict().keys()) == list(g["keys"])
+    head.load_state_dict(w, strict=True)
+    head = head.to(DEV).eval()
+    with torch.no_grad():
+        feat = head(torch.from_numpy(g["tokens"]).to(DEV), normalized=True)
+        feat77 = head(gen.det_tokens("text/tok77", 4).to(DEV), normalized=True)
+    assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
+    assert rel_err(feat77, g["feat77"]) < 2e-2, rel_err(feat77, g["feat77"])
+
+
+def test_image_head_golden(M, golden):
+    g = golden("image_l2")
+    head = M.build_image_head(image_cfg(2))
+    assert sorted(head.state_dict().keys()) == list(g["keys"])
+    head.load_state_dict(gen.det_weights("img/l2", gen.vit_head_shapes(768, 2, 512, 50)), strict=True)
+    head = head.to(DEV).eval()
+    with torch.no_grad():
+        feat = head(gen.det_randn("img/l2/x", (2, 3, 224, 224)).to(DEV), normalized=True)
+    assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
+
+
+@pytest.mark.parametrize("tag,L,b", [("L2", 2, 8), ("L12", 12, 32)])
+def test_end_to_end_golden(M, golden, tag, L, b):
+    """cfg1-shaped VA step (256x64 spectrograms, precomputed image embeddings): features, InfoNCE loss, gradients."""
+    g = golden(f"e2e_{tag}")
+    T, Fq = 256, 64
+    head = M.build_audio_head(audio_cfg(T, Fq, L))
+    S = head.misc.positional_embedding.shape[0]
+    head.load_state_dict(gen.det_weights(f"e2e/{tag}", gen.vit_head_shapes(768, L, 512, S)), strict=True)
+    assert sum(p.numel() for p in head.parameters()) == int(g["n_params"])
+    lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
+    head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
+    from vipant_amd import ops
+    aud = gen.det_randn(f"e2e/{tag}/aud", (b, 1, T, Fq)).to(DEV)
+    img = ops.l2_normalize(gen.det_randn(f"e2e/{tag}/img", (b, 512)).to(DEV))
+    feat = head(aud, normalized=True)
+    loss = lhead(img, feat, None, normalized=True)
+    loss.backward()
+    # features: unit vectors; budget 2 % of the largest component after L bf16 layers (observed < 1 %)
+    assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
+    cos = torch.nn.functional.cosine_similarity(feat.detach().double().cpu(), torch.from_numpy(g["feat"]).double(), dim=-1)
+    assert float(cos.min()) > 0.9995, float(cos.min())
+    # loss: north-star budget 1e-3 is for the K8 boundary (tests/test_kernels_gpu.py); end to end through bf16
+    # towers the stated budget is 5e-3 absolute on a loss of ~2 ln(b)
+    assert abs(float(loss) - float(g["loss"])) < 5e-3, (float(loss), float(g["loss"]))
+    assert abs(float(lhead.logit_scale.grad) - float(g["dls"])) < 2e-2 * max(abs(float(g["dls"])), 1e-3)
+    grads = {k: p.grad for k, p in head.named_parameters()}
+    keys = list(g["keys"])
+    assert keys == sorted(grads.keys())
+    gn = np.array([float(grads[k].norm()) for k in keys])
+    ratio = gn / g["gnorm"]
+    assert np.all(np.abs(ratio - 1) < 5e-2), (keys[int(np.abs(ratio - 1).argmax())], ratio.min(), ratio.max())
+    assert rel_l2(grads["misc.class_embedding"], g["g_cls"]) < 5e-2
+    assert rel_l2(grads["misc.positional_embedding"], g["g_pos"]) < 5e-2
+    assert rel_l2(grads["post_encoder.proj"][::7, ::5], g["g_proj_slice"]) < 5e-2
+    assert rel_l2(grads["pre_encoder.conv1.weight"][::61, :, ::5, ::7], g["g_conv_slice"]) < 5e-2
+    assert rel_l2(grads["encoder.resblocks.0.attn.in_proj_bias"], g["g_b0_qkv_bias"]) < 5e-2
+    assert rel_l2(grads[f"encoder.resblocks.{L - 1}.mlp.c_fc.bias"], g["g_last_fc_bias"]) < 5e-2
+
+
+def test_trainer_step_matches_oracle_lars():
+    """Two Monitor steps on a tiny VA config: loss finite and decreasing bookkeeping, LR schedule values, and the
+    fused LARS update equal to the oracle's per-tensor rule applied to the same gradients."""
+    from oracle import ref_cpu as R
+    from vipant_amd.config import compose
+    from vipant_amd.monitor import VAMonitor
+    ov = ("+running=bimodal worker=CVALP mode=dp eval=False num_gpus=1 +model/image=vit_val +model/audio=vit_val "
+          "+model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=2 running.audio.max_len=256 "
+          "running.audio.num_mel_bins=64 running.batch_size=16 running.epochs=2 running.frame_emb=synthetic "
+          "running.synthetic_steps=2 running.save_epoch=False optimizer.warmup_epoch=1").split()
+    cfg = compose(ov)
+    cfg.rank = 0
+    torch.manual_seed(cfg.seed)
+    logs = []
+    mon = VAMonitor(cfg, logs.append, torch.device(DEV))
+    mon.total_loss = mon.total_step = mon.total_inst = 0
+    import time
+    mon.start_time = time.time()
+    names = [k for k, p in mon.model.named_parameters() if p.requires_grad]
+    params = dict(mon.model.named_parameters())
+    mus = {k: torch.zeros_like(params[k]).cpu() for k in names}
+    step = 0
+    for batch in mon.dataloader:
+        images, audios, text, _, _ = mon.make_batch(batch)
+        from vipant_amd.module import adjust_learning_rate
+        adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, step)
+        lw, lb = R.adjust_learning_rate(step, epochs=2, steps_per_epoch=2, warmup_epoch=1, batch_size=16, lr_weight=0.2,
+                                        lr_bias=0.0048)
+        assert math.isclose(mon.optimizer.param_groups[0]["lr"], lw) and math.isclose(mon.optimizer.param_groups[1]["lr"], lb)
+        before = {k: params[k].detach().cpu().clone() for k in names}
+        # run forward/backward by hand so the gradients can be captured before the optimizer consumes them
+        mon.optimizer.zero_grad(set_to_none=True)
+        loss = mon.model(images, audios, None)
+        loss.backward()
+        grads = {k: params[k].grad.detach().cpu().clone() for k in names}
+        mon.optimizer.step()
+        assert math.isfinite(float(loss)) and abs(float(loss) - 2 * math.log(16)) < 1.0
+        for k in names:
+            p_ref, mus[k] = R.lars_step(before[k], grads[k], mus[k], lw if before[k].ndim > 1 else lb)
+            err = float((params[k].detach().cpu() - p_ref).abs().max())
+            assert err <= 1e-6 + 1e-5 * float(p_ref.abs().max()), (k, step, err)
+        step += 1
+    assert step == 2

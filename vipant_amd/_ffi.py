@@ -9,6 +9,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch must be imported before the library is loaded: libvipant_hip.so depends on libamdhip64.so and has to bind to
+# the HIP runtime torch ships and initialises; loading the system copy first gives the process two runtimes and
+# torch then reports "No HIP GPUs are available".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvipant_hip.so")
 

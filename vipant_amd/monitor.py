@@ -1,0 +1,261 @@
+"""Trainer loop with the reference's Monitor contract (`Monitor(cfg, echo, device).learn()`), reproducing
+the step semantics of VALMonitor.epoch / VAMonitor.epoch (cvap/monitor/cvalp.py:172-272, cvap/monitor/cvap.py:160-244):
+per step -- H2D, LARS learning-rate schedule, zero_grad(set_to_none), forward, backward, optimizer step, counters,
+`samples/s` log line, periodic eval + checkpoint.
+
+Deliberate deviations (documented in DESIGN.md):
+  * bf16 MFMA operands with fp32 accumulation and an fp32 residual stream need no loss scaling, so the reference's
+    fp16 autocast + GradScaler pair (cvalp.py:123, 201-205) has no counterpart here;
+  * one process per GPU: `mode=ddp` is served by vipant_amd.parallel (feature all-gather + bucketed gradient
+    all-reduce); the reference's ddp branch cannot start (train.py:35 names an undefined Monitor);
+  * the reference's dataset builders (cvap/data/*) are outside the hot-path scope; batches come from a synthetic
+    loader with the same tensor contract unless a loader is injected through `dataloader=`.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import parallel
+from .model import build_main_model
+from .module import LARS, adjust_learning_rate, exclude_bias_or_norm
+
+SOT, EOT = 49406, 49407
+
+
+class SyntheticLoader:
+    """Batches with the tensor contract of the reference collators (cvap/data/audioset_clf.py:122-152,
+    cvap/monitor/cvalp.py:136-154): (images, audios [b, T, F], text [b, L] i64, labels, names).  Seeded per rank and
+    per step, reproducible."""
+
+    def __init__(self, cfg, steps, with_text, device_rank=0):
+        self.cfg, self.steps, self.with_text, self.rank = cfg, int(steps), with_text, device_rank
+        rcfg = cfg.running
+        self.b = int(rcfg.batch_size)
+        self.T, self.F = int(rcfg.max_audio_len), int(rcfg.num_mel_bins)
+        self.precomputed = bool(rcfg.get("precomputed_image", False)) or rcfg.get("frame_emb", None) is not None
+        self.res = int(cfg.running.resolution) if not isinstance(cfg.running.resolution, (list, tuple)) else 224
+        self.embed = int(cfg.running.embed_dim)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for step in range(self.steps):
+            g = torch.Generator().manual_seed(1213 + 1000 * self.rank + step)
+            audios = torch.randn(self.b, self.T, self.F, generator=g)
+            if self.with_text:
+                images = torch.zeros(self.b, 1, 1, 1)
+                lens = torch.randint(8, 78, (self.b,), generator=g)
+                L = int(lens.max())
+                text = torch.zeros(self.b, L, dtype=torch.int64)
+                for i in range(self.b):
+                    n = int(lens[i])
+                    text[i, 0] = SOT
+                    text[i, 1:n - 1] = torch.randint(1, SOT, (n - 2,), generator=g)
+                    text[i, n - 1] = EOT
+            else:
+                images = (torch.randn(self.b, self.embed, generator=g) if self.precomputed
+                          else torch.randn(self.b, 3, self.res, self.res, generator=g))
+                text = torch.zeros(self.b, 1, dtype=torch.int64)
+            labels = torch.zeros(self.b, dtype=torch.int64)
+            names = [f"synthetic-{self.rank}-{step}-{i}" for i in range(self.b)]
+            yield images, audios, text, labels, names
+
+
+class Monitor(object):
+    with_text = True      # VALMonitor (AT); VAMonitor sets False
+
+    def __init__(self, cfg, echo, device, dataloader=None):
+        self.cfg, self.echo, self.device = cfg, echo, device
+        self.dataloader = dataloader if dataloader is not None else self.build_data()
+        self.evalloader = self.testloader = None
+        self.gold_file = None
+        model = build_main_model(cfg, echo)
+        negatives = cfg.running.get("negatives", "global")
+        tunable_params = model.build(negatives=negatives)
+        self.model = model
+        self.grad_sync = None
+        if parallel.world_size() > 1:
+            self.grad_sync = parallel.GradSync()
+            for head in (model.audio_head, model.image_head, model.text_head):
+                if head is not None and hasattr(head, "encoder"):
+                    head.encoder.grad_sync = self.grad_sync
+        self.model.train(not cfg.eval)
+        self.build_optimizer(tunable_params)
+
+    def build_data(self):
+        rcfg = self.cfg.running
+        steps = rcfg.get("synthetic_steps", 8)
+        loader = SyntheticLoader(self.cfg, steps, self.with_text, max(self.cfg.rank, 0))
+        self.echo(f"Instantiate main dataloader from `synthetic': total {len(loader)} batches.")
+        return loader
+
+    # ------------------------------------------------------------------ cvalp.py:106-130
+    def learn(self):
+        if not self.model.training:
+            self.echo("Evaluating started...")
+            with torch.no_grad():
+                report = self.infer(self.dataloader, samples=self.cfg.running.eval_samples, gold_file=self.gold_file)
+                self.echo(f"{report}")
+                return None
+        self.echo("Training started...")
+        self.last_time = 0.
+        self.total_loss = 0
+        self.total_step = 0
+        self.total_inst = 0
+        self.start_time = time.time()
+        for iepoch in range(int(self.cfg.optimizer.epochs)):
+            self.epoch(iepoch)
+
+    # ------------------------------------------------------------------ cvalp.py:136-154
+    def make_batch(self, batch):
+        images = torch.as_tensor(batch[0]).to(self.device, non_blocking=True)
+        audios = torch.as_tensor(batch[1]).to(self.device, non_blocking=True).unsqueeze(1)
+        text = torch.as_tensor(batch[2]).to(self.device, non_blocking=True)
+        labels = torch.as_tensor(batch[3]).to(self.device, non_blocking=True)
+        return images, audios, text, labels, batch[-1]
+
+    def timeit(self, time_dict, key=None, show=False):
+        if self.cfg.rank > 0:
+            return
+        if show:
+            report = " ".join(f"{k} {np.mean(v):.2f}" for k, v in time_dict.items())
+            self.echo(f"Time (s): {report}; # step {self.total_step} # sample {self.total_inst}")
+            return
+        if key is None:
+            self.last_time = time.time()
+        else:
+            this_time = time.time()
+            time_dict[key].append(this_time - self.last_time)
+            self.last_time = this_time
+
+    # ------------------------------------------------------------------ one optimisation step
+    def step(self, images, audios, text):
+        """zero_grad -> forward -> backward -> (replica gradient reduction) -> optimizer (cvalp.py:200-205)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model(images, audios, text if self.with_text else None)
+        loss.backward()
+        if self.grad_sync is not None:
+            rest = [p for p in self.params if not getattr(p, "_vipant_bucketed", False)]
+            if self.model.loss_head is not None and self.cfg.running.get("negatives", "global") == "global":
+                skip = {id(p) for p in self.model.loss_head.parameters()}      # complete on every rank already
+                rest = [p for p in rest if id(p) not in skip]
+            self.grad_sync.wait()
+            self.grad_sync.reduce_params(rest)
+        self.optimizer.step()
+        return loss
+
+    # ------------------------------------------------------------------ cvalp.py:172-272
+    def epoch(self, iepoch):
+        all_time = defaultdict(list)
+        self.timeit(all_time)
+        nchunk = parallel.world_size()
+        ocfg = self.cfg.optimizer
+        for step, batch in enumerate(self.dataloader, start=iepoch * len(self.dataloader)):
+            images, audios, text, _, _ = self.make_batch(batch)
+            self.timeit(all_time, key="data")
+            if ocfg.use_lars:
+                adjust_learning_rate(ocfg, self.optimizer, self.dataloader, step)
+            loss = self.step(images, audios, text)
+            self.timeit(all_time, key="model")
+            self.total_step += 1
+            self.total_loss += loss.detach()
+            self.total_inst += images.shape[0] * nchunk
+            if self.cfg.rank <= 0 and self.total_step % self.cfg.running.peep_rate == 0:
+                lr_w = self.optimizer.param_groups[0]["lr"]
+                lr_b = self.optimizer.param_groups[1]["lr"]
+                msg = self.model.report(**{"nstep": self.total_step})
+                self.echo(
+                    f"epoch {iepoch:>4} step {self.total_step}\t"
+                    f"lr_w {lr_w:.2e} lr_b {lr_b:.2e} loss {float(self.total_loss) / self.total_step:.3f} "
+                    f"{msg} {self.total_inst / (time.time() - self.start_time):.2f} samples/s"
+                )
+            if self.total_step % self.cfg.running.save_rate == 0 or (
+                    self.cfg.running.save_epoch and self.total_step % len(self.dataloader) == 0):
+                for loader, samples in ((self.evalloader, self.cfg.running.eval_samples),
+                                        (self.testloader, self.cfg.running.test_samples)):
+                    if loader is None:
+                        continue
+                    self.model.train(False)
+                    with torch.no_grad():
+                        report = self.infer(loader, samples=samples, iepoch=iepoch, gold_file=self.gold_file)
+                    self.model.train(True)
+                    if report != "":
+                        self.echo(f"{report}")
+                if self.cfg.rank <= 0:
+                    self.save()
+            self.timeit(all_time, key="report")
+        self.timeit(all_time, show=True)
+
+    # ------------------------------------------------------------------ cvalp.py:274-300
+    def infer(self, dataloader, samples=float("inf"), iepoch=0, gold_file=None):
+        nsample, nchunk = 0, 1
+        start_time = time.time()
+        for ibatch, batch in enumerate(dataloader):
+            if nsample >= samples:
+                break
+            images, audios, text, _, names = self.make_batch(batch)
+            self.model(images, audios, text if self.with_text else None, names=names)
+            nsample += images.shape[0] * nchunk
+        self.echo(f"# sample {nsample}; {nsample / (time.time() - start_time):.2f} samples/s")
+        return self.model.report(gold_file=gold_file)
+
+    # ------------------------------------------------------------------ cvalp.py:302-309
+    def save(self):
+        from .config import to_plain
+        out_dir = f"{self.cfg.alias_root}/{self.cfg.model_name}"
+        os.makedirs(out_dir, exist_ok=True)
+        fsave = f"{out_dir}/{self.total_step:08d}.pth"
+        self.echo(f"Saving the checkpoint to {fsave}")
+        torch.save({"cfg": to_plain(self.cfg), "model": self.model.collect_audio_state_dict()}, fsave)
+
+    # ------------------------------------------------------------------ cvalp.py:311-348
+    def build_optimizer(self, tunable_params={}):
+        if not self.model.training:
+            return
+        self.params = list(tunable_params.values())
+        for k, v in self.model.named_parameters():
+            if k not in tunable_params:
+                v.requires_grad = False
+        ntotal = sum(p.numel() for p in self.model.parameters())
+        ntune = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+        self.echo(f"# param {ntotal / 1e6:.2f}M # tunable {ntune / 1e6:.2f}M.")
+        # transformer-stack parameters are reduced per layer by the backward itself (parallel.GradSync)
+        for head in (self.model.audio_head, self.model.image_head, self.model.text_head):
+            if head is not None and hasattr(head, "encoder"):
+                for p in head.encoder.parameters():
+                    p._vipant_bucketed = True
+        param_groups = [
+            {"params": [p for p in self.params if p.ndim > 1]},
+            {"params": [p for p in self.params if p.ndim < 2]},
+        ]
+        ocfg = self.cfg.optimizer
+        if ocfg.use_lars:
+            self.optimizer = LARS(param_groups, lr=0., weight_decay=ocfg.weight_decay,
+                                  weight_decay_filter=exclude_bias_or_norm, lars_adaptation_filter=exclude_bias_or_norm)
+        else:
+            raise NotImplementedError("only the LARS branch (optimizer.use_lars=True, the default of both launch scripts) "
+                                      "is on the accelerated path")
+        if self.cfg.verbose:
+            self.echo("Gradienting The Following Parameters:")
+            for k, v in self.model.named_parameters():
+                if v.requires_grad:
+                    self.echo(f"{k} {tuple(v.size())}")
+
+
+class VALMonitor(Monitor):
+    """AT fine-tuning trainer (cvap/monitor/cvalp.py:23)."""
+    with_text = True
+
+
+class VAMonitor(Monitor):
+    """VA pre-training trainer (cvap/monitor/cvap.py:21)."""
+    with_text = False
+
+
+__all__ = ["Monitor", "VAMonitor", "VALMonitor", "SyntheticLoader"]

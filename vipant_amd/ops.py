@@ -46,6 +46,10 @@ def _need(t: torch.Tensor, dtype, name: str):
 
 _scratch: Dict[Tuple[str, int], torch.Tensor] = {}
 
+# bench.py hooks a probe here to bracket selected kernel launches with HIP events on the launch stream
+# (kernels are launched on torch's current stream, so torch.cuda.Event records on the right queue).
+KERNEL_PROBE: Dict[str, dict] = {}
+
 
 def scratch(name: str, nbytes: int, device) -> torch.Tensor:
     """Named, grow-only byte workspace (256-B aligned by the caching allocator)."""
@@ -67,8 +71,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux
     assert b.shape[1] == K and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
     if aux is not None:
         assert aux.stride(0) == c.stride(0)
+    probe = KERNEL_PROBE.get("gemm_nt")
+    if probe is not None and probe["match"](epi, M, N, K):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    else:
+        probe = None
     call("vipant_gemm_nt", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
          _ptr(bias), _ptr(aux), float(alpha), M, N, K, epi, _stream())
+    if probe is not None:
+        e1.record()
+        probe["events"].append((e0, e1))
     return c
 
 
@@ -444,6 +457,29 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     norm = torch.empty((x.shape[0],), dtype=F32, device=x.device)
     call("vipant_l2norm_fwd", x.data_ptr(), out.data_ptr(), norm.data_ptr(), x.shape[0], x.shape[1], _stream())
     return out
+
+
+class L2NormFn(torch.autograd.Function):
+    """x / ||x|| (cvap/module/decoder/loss_head.py:272-273) with its backward, for un-normalised head outputs."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need(x, F32, "l2norm.x")
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        norm = torch.empty((x.shape[0],), dtype=F32, device=x.device)
+        call("vipant_l2norm_fwd", x.data_ptr(), out.data_ptr(), norm.data_ptr(), x.shape[0], x.shape[1], _stream())
+        ctx.save_for_backward(out, norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, norm = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty_like(out)
+        call("vipant_l2norm_bwd", dout.data_ptr(), out.data_ptr(), norm.data_ptr(), dx.data_ptr(), None, out.shape[0],
+             out.shape[1], _stream())
+        return dx
 
 
 # ---------------------------------------------------------------------------------- InfoNCE

@@ -1,0 +1,106 @@
+"""Data-parallel replicas: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" in
+the CPU tests).  The path shards by samples; there are exactly two exchange steps:
+
+  1. all-gather of the two [b, E] feature blocks before the loss, so that every rank scores the GLOBAL batch
+     (the reference's dp-mode semantics, cvap/model/cvalp.py:41-61).  Every rank evaluates the full B x B loss and
+     the fused kernel emits gradients only for the rank's own rows, so the backward of the gather is a slice --
+     no reduce-scatter;
+  2. gradient all-reduce (SUM): each rank holds dL/d(theta) through its own samples only.  The transformer stack
+     hands each layer's gradients over as ONE flat fp32 buffer the moment that layer's backward is finished
+     (ops.BackboneFn), so the reduction of layer l overlaps the backward of layers < l on a side stream.
+     `logit_scale` is different: every rank computes its complete gradient, so it is never reduced in
+     global-negatives mode.
+
+Device-agnostic on purpose: the same code runs under gloo on CPU tensors in tests/test_parallel_cpu.py.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if is_dist() else 0
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[b, C] per rank -> [world * b, C]; backward keeps this rank's rows (see module docstring)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        w = world_size()
+        out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather(list(out.chunk(w, dim=0)), x)
+        ctx.b = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        r = rank()
+        return g[r * ctx.b:(r + 1) * ctx.b].contiguous()
+
+
+def all_gather_features(x1: torch.Tensor, x2: torch.Tensor):
+    """One collective for both modalities: gathers [b, 2E], returns the two [B, E] halves (contiguous)."""
+    E = x1.shape[1]
+    both = _AllGatherRows.apply(torch.cat([x1, x2], dim=1))
+    return both[:, :E].contiguous(), both[:, E:].contiguous()
+
+
+class GradSync:
+    """Asynchronous SUM all-reduce of gradient buckets on a side stream."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.handles: List = []
+        self.buffers: List[torch.Tensor] = []
+        self.stream: Optional[torch.cuda.Stream] = None
+
+    def _comm_stream(self, device):
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=device)
+        return self.stream
+
+    def reduce_async(self, flat: torch.Tensor):
+        if world_size() == 1:
+            return
+        if flat.is_cuda:
+            comm = self._comm_stream(flat.device)
+            comm.wait_stream(torch.cuda.current_stream(flat.device))    # bucket is complete on the compute stream
+            with torch.cuda.stream(comm):
+                self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            flat.record_stream(comm)
+        else:
+            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.buffers.append(flat)
+
+    def reduce_params(self, params: Iterable[torch.nn.Parameter]):
+        """Bucket the (small) gradients that did not come through a layer bucket: patch embedding, read-out."""
+        grads = [p.grad for p in params if p.grad is not None]
+        if world_size() == 1 or not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self.reduce_async(flat)
+        self.wait()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.handles, self.buffers = [], []
