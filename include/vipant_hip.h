@@ -68,17 +68,24 @@ int32_t vipant_colsum_bf16(const uint16_t* X, int64_t ldx, float* out, int64_t M
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm (clip/model.py:154-160: fp32 statistics, eps 1e-5) -----------------------------------
- * x fp32 rows (row stride ldx elements) -> y bf16 [M, D]; mean / rstd fp32 [M] saved for backward.
- * y_f32 (optional, may be NULL) receives the fp32 result as well (ln_pre writes the residual stream). */
+ * x fp32 rows (row stride ldx elements) -> y bf16 [M, D] (optional); mean / rstd fp32 [M] saved for backward.
+ * y_f32 (optional, may be NULL) receives the fp32 result as well (ln_pre writes the residual stream).
+ * add (optional bf16 [M, D]): the residual add `x + branch` of ResidualAttentionBlock.forward (cvap/module/val.py:520-521)
+ * fused in front of the norm; sum_out (optional fp32 [M, D]) receives x + add (the new residual stream). */
 int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y,
-                             float* y_f32, float* mean, float* rstd, int64_t M, int64_t D, void* stream);
+                             float* y_f32, float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add,
+                             float* sum_out, void* stream);
+/* out fp32 [M, D] = x fp32 + add bf16 (the last block's residual add, no norm behind it). */
+int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int64_t n, void* stream);
 /* dx_f32[M,D] = dres (optional fp32 residual-stream gradient, may alias dx) + LN'(dy); dx_bf16 optional.
- * dy is bf16 [M,D] when dy_is_f32 == 0, fp32 otherwise.  dgamma / dbeta fp32 [D] (+)= column reductions. */
+ * dy is bf16 [M,D] when dy_is_f32 == 0, fp32 otherwise.  dgamma / dbeta fp32 [D] (+)= column reductions;
+ * dx_colsum (optional fp32 [D]) (+)= sum over rows of the produced dx: the bias gradient of the Linear whose
+ * output gradient this dx is (out_proj / c_proj), for free in the same pass. */
 size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
 int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx, const float* mean,
                              const float* rstd, const float* gamma, const float* dres, float* dx_f32, int64_t lddx,
-                             uint16_t* dx_bf16, float* dgamma, float* dbeta, int32_t accumulate, int64_t M,
-                             int64_t D, void* workspace, size_t workspace_bytes, void* stream);
+                             uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t accumulate,
+                             int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- multi-head attention core (nn.MultiheadAttention inside ResidualAttentionBlock,
  *      cvap/module/val.py:511-517): softmax(q k^T / sqrt(64) [+ causal mask]) v, head dim 64 -----------

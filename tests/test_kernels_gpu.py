@@ -161,7 +161,9 @@ def test_layernorm(ops, M, D):
     ref.backward(dy.double())
     dx = torch.empty(M, D, device=DEV); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
     dg = torch.empty(D, device=DEV); db = torch.empty(D, device=DEV)
-    ops.layernorm_bwd(dy, x, mean, rstd, gm, dres=dres, dx=dx, dx_bf16=dxb, dgamma=dg, dbeta=db)
+    dcs = torch.empty(D, device=DEV)
+    ops.layernorm_bwd(dy, x, mean, rstd, gm, dres=dres, dx=dx, dx_bf16=dxb, dgamma=dg, dbeta=db, dx_colsum=dcs)
+    assert_close(dcs, (xr.grad + dres.double()).sum(0), 1e-4, 1e-3 * math.sqrt(M), "ln bwd dx colsum")
     assert_close(dx, xr.grad + dres.double(), 1e-4, 1e-4, "ln bwd dx")
     assert_close(dxb, xr.grad + dres.double(), 1e-2, 1e-2, "ln bwd dx bf16")
     assert_close(dg, gmr.grad, 1e-4, 1e-3 * math.sqrt(M), "ln bwd dgamma")
@@ -296,3 +298,14 @@ def test_lars_golden(ops, golden):
         if step in (0, 1, 5, 11):
             for i, p in enumerate(ps):
                 assert_close(p, torch.from_numpy(g[f"p{i}_{step}"]), 1e-5, 1e-6, f"lars p{i} step {step}")
+
+
+def test_layernorm_fused_residual_add(ops):
+    M, D = 1000, 768
+    x = rnd(M, D, seed=1); y = rnd(M, D, seed=2, dtype=torch.bfloat16)
+    gm = rnd(D, seed=3, scale=0.1) + 1.0; bt = rnd(D, seed=4, scale=0.1)
+    h, _, mean, rstd, xs = ops.layernorm_fwd(x, gm, bt, add=y, want_sum=True)
+    ref_sum = x.double() + y.double()
+    assert_close(xs, ref_sum, 1e-6, 1e-6, "x + branch")
+    assert_close(h, torch.nn.functional.layer_norm(ref_sum, (D,), gm.double(), bt.double(), 1e-5), 1e-2, 1e-2, "ln(x + branch)")
+    assert_close(ops.residual_add(x, y), ref_sum, 1e-6, 1e-6, "residual_add")

@@ -31,9 +31,10 @@ PROTOTYPES = {
     "vipant_gemm_tn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "vipant_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_colsum_bf16": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _sz, _p]),
-    "vipant_layernorm_fwd": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "vipant_layernorm_fwd": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "vipant_residual_add": (_i32, [_p, _p, _p, _i64, _p]),
     "vipant_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
-    "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
+    "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),

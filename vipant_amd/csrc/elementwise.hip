@@ -39,6 +39,14 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void residual_add_kernel(const float* __restrict__ x, const bf16_t* __restrict__ add,
+                                                           float* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const bf16x4 a = *(const bf16x4*)(add + i * 4);
+        *(f32x4*)(out + i * 4) = *(const f32x4*)(x + i * 4) + f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+    }
+}
+
 // ---- conv1.weight -> GEMM weight ---------------------------------------------------------------------
 __global__ void conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int64_t O, int Cin,
                                         int khw, int mean_channels) {
@@ -261,6 +269,14 @@ extern "C" int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* d
         hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(C, 64), (unsigned)ceil_div(R, 64)), dim3(256), 0,
                            s, src, (bf16_t*)dst, (bf16_t*)dst_t, (int)R, (int)C);
     }
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int64_t n, void* stream) {
+    VIPANT_REQUIRE(n > 0 && n % 4 == 0, VIPANT_EBADSHAPE, "residual_add: numel must be a positive multiple of 4");
+    hipLaunchKernelGGL(residual_add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const bf16_t*)add, out, n / 4);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int64_t M) {
+                                                     float* __restrict__ rstd, int64_t M,
+                                                     const bf16_t* __restrict__ add, float* __restrict__ sum_out) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -30,6 +31,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             v[t] = *(const f32x4*)(xr + (t * 64 + lane) * 4);
+            if (add != nullptr) {      // residual add fused in front of the norm: v = x + branch (bf16)
+                const bf16x4 a4 = *(const bf16x4*)(add + row * D + (t * 64 + lane) * 4);
+                v[t] += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+                if (sum_out != nullptr) *(f32x4*)(sum_out + row * D + (t * 64 + lane) * 4) = v[t];
+            }
             s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
         }
         const float mu = wave_sum(s) * (1.0f / D);
@@ -60,16 +66,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* dres, float* dx, int64_t lddx,
                                                      bf16_t* __restrict__ dxb, float* __restrict__ partial, int64_t M) {
     constexpr int D = NV * 256;
-    __shared__ float red[4 * 2 * D > 0 ? 4 * 2 * D : 1];
+    __shared__ float red[4 * 3 * D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    f32x4 gv[NV], dg[NV], db[NV];
+    f32x4 gv[NV], dg[NV], db[NV], dsum[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         gv[t] = *(const f32x4*)(gamma + (t * 64 + lane) * 4);
         dg[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int64_t row = wave; row < M; row += nwaves) {
         const float mu = mean[row], rs = rstd[row];
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             const int col = (t * 64 + lane) * 4;
             f32x4 o = (g[t] - s1 - xh[t] * s2) * rs;
             if (dres != nullptr) o += *(const f32x4*)(dres + row * lddx + col);
+            dsum[t] += o;
             if (dx != nullptr) *(f32x4*)(dx + row * lddx + col) = o;
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
         }
@@ -106,34 +114,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     // block reduction of the 4 waves' partial column sums, then one row of partials per block
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        *(f32x4*)(red + (wv * 2 + 0) * D + (t * 64 + lane) * 4) = dg[t];
-        *(f32x4*)(red + (wv * 2 + 1) * D + (t * 64 + lane) * 4) = db[t];
+        *(f32x4*)(red + (wv * 3 + 0) * D + (t * 64 + lane) * 4) = dg[t];
+        *(f32x4*)(red + (wv * 3 + 1) * D + (t * 64 + lane) * 4) = db[t];
+        *(f32x4*)(red + (wv * 3 + 2) * D + (t * 64 + lane) * 4) = dsum[t];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256)
-        partial[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+    for (int i = threadIdx.x; i < 3 * D; i += 256)
+        partial[(int64_t)blockIdx.x * 3 * D + i] = red[i] + red[3 * D + i] + red[6 * D + i] + red[9 * D + i];
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D, float* dgamma,
-                                       float* dbeta, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * D) return;
+// One workgroup per 64 columns: 4 row-lanes x 64 column-lanes sweep the per-block partials, LDS-reduce the 4 lanes.
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                              float* dgamma, float* dbeta, float* dxcolsum,
+                                                              int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;          // index into the [3 * D] (dgamma | dbeta | colsum dx) vector
+    const int lim = dxcolsum != nullptr ? 3 * D : 2 * D;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * D + i];
-    float* dst = i < D ? dgamma + i : dbeta + (i - D);
-    *dst = accumulate ? *dst + s : s;
+    if (i < lim)
+        for (int b = ty; b < nblocks; b += 4) s += partial[(int64_t)b * 3 * D + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < lim) {
+        s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        float* dst = i < D ? dgamma + i : (i < 2 * D ? dbeta + (i - D) : dxcolsum + (i - 2 * D));
+        *dst = accumulate ? *dst + s : s;
+    }
 }
 
 int ln_blocks(int64_t M) {
     int64_t b = ceil_div(M, 4);
-    return (int)(b > 1024 ? 1024 : b);
+    return (int)(b > 512 ? 512 : b);
 }
 
 }  // namespace
 
 extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                         uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
-                                        void* stream) {
+                                        const uint16_t* add, float* sum_out, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
                    "layernorm_fwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
     VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
@@ -141,7 +160,7 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
     const int blocks = (int)(ceil_div(M, 4) > 2048 ? 2048 : ceil_div(M, 4));
 #define LN_FWD(NV)                                                                                                   \
     hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, y_f32, mean, \
-                       rstd, M)
+                       rstd, M, (const bf16_t*)add, sum_out)
     switch (D / 256) {
         case 1: LN_FWD(1); break;
         case 2: LN_FWD(2); break;
@@ -154,13 +173,13 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
 }
 
 extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
-    return (size_t)ln_blocks(M) * 2 * (size_t)D * sizeof(float);
+    return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx,
                                         const float* mean, const float* rstd, const float* gamma, const float* dres,
                                         float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
-                                        int32_t accumulate, int64_t M, int64_t D, void* workspace,
+                                        float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
                                         size_t workspace_bytes, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
                    "layernorm_bwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
@@ -187,8 +206,8 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const
     }
 #undef LN_BWD
     VIPANT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(2 * D, 256)), dim3(256), 0, s,
-                       (const float*)partial, blocks, (int)D, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(256), 0, s,
+                       (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

@@ -108,8 +108,9 @@ def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, *, want_bf16=True, want_f32=False, rows: Optional[int] = None,
-                  ldx: Optional[int] = None):
-    """x fp32 [M, D] (or `rows` rows with stride `ldx`) -> (y_bf16 | None, y_f32 | None, mean, rstd)."""
+                  ldx: Optional[int] = None, add: Optional[torch.Tensor] = None, want_sum=False):
+    """x fp32 [M, D] (or `rows` rows with stride `ldx`) -> (y_bf16 | None, y_f32 | None, mean, rstd[, x + add]).
+    `add` (bf16 [M, D]) fuses the block's residual add in front of the norm; want_sum returns the new stream."""
     _need(x, F32, "layernorm_fwd.x")
     D = x.shape[-1]
     M = rows if rows is not None else x.shape[0]
@@ -118,13 +119,22 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, *, want_bf16=True, want_f32=Fals
     y32 = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
     mean = torch.empty((M,), dtype=F32, device=x.device)
     rstd = torch.empty((M,), dtype=F32, device=x.device)
+    xsum = torch.empty((M, D), dtype=F32, device=x.device) if (add is not None and want_sum) else None
     call("vipant_layernorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32),
-         mean.data_ptr(), rstd.data_ptr(), M, D, _stream())
+         mean.data_ptr(), rstd.data_ptr(), M, D, _ptr(add), _ptr(xsum), _stream())
+    if add is not None:
+        return y, y32, mean, rstd, xsum
     return y, y32, mean, rstd
 
 
+def residual_add(x: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    call("vipant_residual_add", x.data_ptr(), add.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=None, dx=None, lddx=None,
-                  dx_bf16=None, dgamma, dbeta, accumulate=False, rows=None, ldx=None):
+                  dx_bf16=None, dgamma, dbeta, dx_colsum=None, accumulate=False, rows=None, ldx=None):
     D = x.shape[-1]
     M = rows if rows is not None else x.shape[0]
     ldx = ldx if ldx is not None else x.stride(0)
@@ -132,7 +142,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=
     ws = scratch("ln_bwd", query("vipant_layernorm_bwd_workspace_bytes", M, D), x.device)
     call("vipant_layernorm_bwd", dy.data_ptr(), int(dy.dtype == F32), x.data_ptr(), ldx, mean.data_ptr(),
          rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), _ptr(dx), lddx, _ptr(dx_bf16), dgamma.data_ptr(),
-         dbeta.data_ptr(), int(accumulate), M, D, ws.data_ptr(), ws.numel(), _stream())
+         dbeta.data_ptr(), _ptr(dx_colsum), int(accumulate), M, D, ws.data_ptr(), ws.numel(), _stream())
 
 
 def mha_fwd(qkv: torch.Tensor, batch: int, S: int, H: int, causal: bool):
@@ -277,11 +287,17 @@ class BackboneFn(torch.autograd.Function):
         saved: List[torch.Tensor] = []
         wts: List[Tuple[torch.Tensor, ...]] = []
         x = x.contiguous()
-        if not train:   # frozen tower: one pair of residual buffers and one set of temporaries for all layers
+        # Per block (cvap/module/val.py:519-522):  x1 = x + attn(ln_1(x));  x2 = x1 + mlp(ln_2(x1)).
+        # The branch outputs y1, y2 leave their contraction as bf16 and the residual add is fused into the NEXT
+        # LayerNorm pass (fp32 stream in, fp32 stream + bf16 normalised activations out), so every contraction has a
+        # plain single-output bf16 epilogue and the fp32 stream is only touched by the streaming LN kernels.
+        if not train:   # frozen tower: one set of temporaries for all layers
             qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
             u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
             g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-            xa, xb = torch.empty_like(x), torch.empty_like(x)
+            y1 = torch.empty((M, D), dtype=BF16, device=dev)
+            y2 = torch.empty((M, D), dtype=BF16, device=dev)
+        y_prev = None
         for l in range(L):
             ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
             if train:
@@ -291,20 +307,24 @@ class BackboneFn(torch.autograd.Function):
                 qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
                 u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
                 g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-                x1, x2 = torch.empty_like(x), torch.empty_like(x)
+                y1 = torch.empty((M, D), dtype=BF16, device=dev)
+                y2 = torch.empty((M, D), dtype=BF16, device=dev)
             else:
                 wqkv_b, wo_b, wfc_b, wpr_b = (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
-                x1, x2 = xa, xb
-            h1, _, mean1, rstd1 = layernorm_fwd(x, ln1w, ln1b)
+            if y_prev is None:
+                h1, _, mean1, rstd1 = layernorm_fwd(x, ln1w, ln1b)
+            else:       # x <- x1_prev + y2_prev, fused with ln_1 of this block
+                h1, _, mean1, rstd1, x = layernorm_fwd(x, ln1w, ln1b, add=y_prev, want_sum=True)
             gemm_nt(h1, wqkv_b, qkv, bias=bqkv, epi=EPI_BF16)
             o, lse = mha_fwd(qkv, batch, S, H, causal)
-            gemm_nt(o, wo_b, x1, bias=bo, aux=x, epi=EPI_RESIDUAL_F32)
-            h2, _, mean2, rstd2 = layernorm_fwd(x1, ln2w, ln2b)
+            gemm_nt(o, wo_b, y1, bias=bo, epi=EPI_BF16)
+            h2, _, mean2, rstd2, x1 = layernorm_fwd(x, ln2w, ln2b, add=y1, want_sum=True)
             gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
-            gemm_nt(g, wpr_b, x2, bias=bpr, aux=x1, epi=EPI_RESIDUAL_F32)
+            gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             if train:
                 saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g]
-            x = x2
+            x, y_prev = x1, y2
+        x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
@@ -322,32 +342,33 @@ class BackboneFn(torch.autograd.Function):
         M, D = dx.shape
         dx_b = cast_bf16_flat(dx)
         grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
+        lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
+        colsum(dx_b, lg.views[11])          # d c_proj.bias of the top block; lower blocks get theirs from ln_1's backward
         for l in reversed(range(L)):
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g = saved[13 * l:13 * l + 13]
             ln1w, _, _, _, _, _, ln2w, _, _, _, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
             wqkv_t, wo_t, wfc_t, wpr_t = ctx.wts[l]
-            lg = _LayerGrads([p.shape for p in params[12 * l:12 * l + 12]], dev)
             (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
+            lg_below = _LayerGrads([p.shape for p in params[12 * (l - 1):12 * l]], dev) if l > 0 else None
             # c_proj + QuickGELU'
             du = torch.empty((M, 4 * D), dtype=BF16, device=dev)
             gemm_nt(dx_b, wpr_t, du, aux=u, epi=EPI_DQUICKGELU)
             gemm_tn(dx_b, g, d_wpr)
-            colsum(dx_b, d_bpr)
             # c_fc
             dh2 = torch.empty((M, D), dtype=BF16, device=dev)
             gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
             gemm_tn(du, h2, d_wfc)
             colsum(du, d_bfc)
             del du
-            # ln_2 (+ residual gradient)
+            # ln_2 (+ residual gradient); its output dx1 is also d(out_proj output): column sum = d out_proj.bias
             dx1 = torch.empty((M, D), dtype=F32, device=dev)
             dx1_b = torch.empty((M, D), dtype=BF16, device=dev)
-            layernorm_bwd(dh2, x1, mean2, rstd2, ln2w, dres=dx, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln2w, dbeta=d_ln2b)
+            layernorm_bwd(dh2, x1, mean2, rstd2, ln2w, dres=dx, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln2w, dbeta=d_ln2b,
+                          dx_colsum=d_bo)
             # out_proj
             do = dh2
             gemm_nt(dx1_b, wo_t, do, epi=EPI_BF16)
             gemm_tn(dx1_b, o, d_wo)
-            colsum(dx1_b, d_bo)
             # attention core
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
             # in_proj
@@ -356,13 +377,16 @@ class BackboneFn(torch.autograd.Function):
             gemm_tn(dqkv, h1, d_wqkv)
             colsum(dqkv, d_bqkv)
             del dqkv
-            # ln_1 (+ residual gradient); reuse the stream buffers in place
-            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln1w, dbeta=d_ln1b)
+            # ln_1 (+ residual gradient), in place on the stream buffers; the produced dx is d(c_proj output) of the
+            # block below: its column sum is that block's d c_proj.bias
+            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln1w, dbeta=d_ln1b,
+                          dx_colsum=lg_below.views[11] if lg_below is not None else None)
             dx, dx_b = dx1, dx1_b
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
             if ctx.grad_sync is not None:
                 ctx.grad_sync.reduce_async(lg.flat)
+            lg = lg_below
         ctx.wts = None
         need = ctx.needs_input_grad
         out_grads = [gr if need[5 + i] else None for i, gr in enumerate(grads)]
