@@ -1,0 +1,82 @@
+"""The C ABI: libvipant_hip.so loads (no GPU needed), exports every symbol include/vipant_hip.h declares, the
+ctypes table mirrors the header one to one, and the product path refuses CPU tensors instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vipant_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vipant_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vipant_amd import _ffi, build
+    build.build(verbose=False)
+    lib = _ffi.lib()
+    syms = header_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vipant_hip.h but not exported"
+    assert sorted(_ffi.PROTOTYPES.keys()) == syms, set(_ffi.PROTOTYPES) ^ set(syms)
+    assert lib.vipant_version() == 100
+    assert lib.vipant_last_error() is not None
+
+
+def test_argument_counts_match_header():
+    from vipant_amd import _ffi
+    text = open(os.path.join(ROOT, "include", "vipant_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, (_, args) in _ffi.PROTOTYPES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
+def test_workspace_queries_run_without_a_gpu():
+    from vipant_amd import _ffi
+    assert _ffi.query("vipant_gemm_tn_workspace_bytes", 161792, 3072, 768) == 7 * 36 * 256 * 256 * 4
+    assert _ffi.query("vipant_infonce_workspace_bytes", 4096, 512) > 4096 * 4096 * 2
+    assert _ffi.query("vipant_lars_workspace_bytes", 153) == 153 * 32 * 2 * 4
+    assert _ffi.query("vipant_layernorm_bwd_workspace_bytes", 161792, 768) == 512 * 3 * 768 * 4
+    assert _ffi.query("vipant_colsum_workspace_bytes", 1000, 768) == 128 * 768 * 4
+
+
+def test_bad_arguments_are_reported_not_executed():
+    from vipant_amd import _ffi
+    with pytest.raises(_ffi.VipantError, match="K%64"):
+        _ffi.call("vipant_gemm_nt", 16, 100, 16, 100, 16, 64, None, None, 1.0, 4, 64, 100, 0, None)
+    with pytest.raises(_ffi.VipantError, match="sequence length"):
+        _ffi.call("vipant_mha_fwd", 16, 16, 16, 1, 1000, 12, 0, None)
+    with pytest.raises(_ffi.VipantError, match="workspace"):
+        _ffi.call("vipant_infonce_fwd_bwd", 16, 16, 16, 0.0, 16, None, None, None, 1.0, 64, 512, 0, 64, None, 0, None)
+
+
+def test_no_cpu_fallback():
+    from vipant_amd import _ffi, ops
+    a = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(_ffi.VipantError, match="no CPU fallback"):
+        ops.gemm_nt(a, a, torch.zeros(4, 4, dtype=torch.bfloat16))
+    with pytest.raises(_ffi.VipantError, match="no CPU fallback"):
+        ops.InfoNCEFn.apply(torch.zeros(8, 512), torch.zeros(8, 512), torch.zeros(()), 0.0, 0, 8, 1.0)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vipant_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "ref_cpu" in src:
+                    bad.append(os.path.join(dirpath, f))
+    for f in ("train.py",):
+        if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, f)).read(), flags=re.M):
+            bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,107 @@
+"""Replica logic (vipant_amd/parallel.py) under torch.distributed "gloo", world_size 2, on CPU tensors.
+
+The towers here are a tiny differentiable stand-in and the loss is the CPU oracle, because HIP kernels cannot run in
+this container; what is under test is the exchange scheme itself: feature all-gather whose backward is a slice,
+SUM all-reduce of per-layer gradient buckets, no reduction of logit_scale -- and the invariant it must deliver:
+N replicas on a split batch == one process on the whole batch (the reference's dp-mode semantics)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as R
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tower(x, w):
+    f = torch.tanh(x @ w)
+    return f / f.norm(dim=-1, keepdim=True)
+
+
+def _data(B=16, Din=24, E=64):
+    g = torch.Generator().manual_seed(7)
+    xa, xt = torch.randn(B, Din, generator=g), torch.randn(B, Din, generator=g)
+    wa, wt = torch.randn(Din, E, generator=g) * 0.3, torch.randn(Din, E, generator=g) * 0.3
+    return xa, xt, wa, wt
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vipant_amd import parallel
+        assert parallel.world_size() == world and parallel.rank() == rank
+        xa, xt, wa0, wt0 = _data()
+        B = xa.shape[0]
+        b = B // world
+        sl = slice(rank * b, (rank + 1) * b)
+        res = {}
+        # ---- global negatives: gather features, loss on the full batch, slice backward, SUM reduce
+        wa, wt = wa0.clone().requires_grad_(), wt0.clone().requires_grad_()
+        ls = torch.tensor(2.0, requires_grad=True)
+        fa, ft = _tower(xa[sl], wa), _tower(xt[sl], wt)
+        ga, gt = parallel.all_gather_features(fa, ft)
+        assert ga.shape == (B, 64) and torch.allclose(ga[sl], fa.detach())
+        loss = R.ce_loss_head(ga, gt, ls)
+        loss.backward()
+        sync = parallel.GradSync()
+        flat = torch.cat([wa.grad.reshape(-1), wt.grad.reshape(-1)])
+        sync.reduce_async(flat)
+        sync.wait()
+        res["global"] = (loss.detach(), flat.clone(), ls.grad.clone())
+        # ---- local negatives (cfg3: "DDP grad all-reduce only"): mean of per-rank losses
+        wa, wt = wa0.clone().requires_grad_(), wt0.clone().requires_grad_()
+        ls2 = torch.tensor(2.0, requires_grad=True)
+        loss_l = R.ce_loss_head(_tower(xa[sl], wa), _tower(xt[sl], wt), ls2) / world
+        loss_l.backward()
+        sync.reduce_params([wa, wt, ls2])
+        res["local"] = (wa.grad.clone(), wt.grad.clone(), ls2.grad.clone())
+        if rank == 0:
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_replicas_equal_one_process(tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    xa, xt, wa0, wt0 = _data()
+    # single process, whole batch
+    wa, wt = wa0.clone().requires_grad_(), wt0.clone().requires_grad_()
+    ls = torch.tensor(2.0, requires_grad=True)
+    loss = R.ce_loss_head(_tower(xa, wa), _tower(xt, wt), ls)
+    loss.backward()
+    gl, gflat, gls = res["global"]
+    assert torch.allclose(gl, loss.detach(), atol=1e-6)
+    assert torch.allclose(gflat, torch.cat([wa.grad.reshape(-1), wt.grad.reshape(-1)]), atol=1e-6)
+    assert torch.allclose(gls, ls.grad, atol=1e-6)          # complete on every rank without any reduction
+    # local negatives == mean over ranks of the per-rank objective
+    wa, wt = wa0.clone().requires_grad_(), wt0.clone().requires_grad_()
+    ls = torch.tensor(2.0, requires_grad=True)
+    tot = 0
+    for r in range(2):
+        sl = slice(r * 8, (r + 1) * 8)
+        tot = tot + R.ce_loss_head(_tower(xa[sl], wa), _tower(xt[sl], wt), ls) / 2
+    tot.backward()
+    la, lt, lls = res["local"]
+    assert torch.allclose(la, wa.grad, atol=1e-6) and torch.allclose(lt, wt.grad, atol=1e-6)
+    assert torch.allclose(lls, ls.grad, atol=1e-6)
+
+
+def test_single_process_is_a_no_op():
+    from vipant_amd import parallel
+    assert parallel.world_size() == 1 and parallel.rank() == 0
+    s = parallel.GradSync()
+    t = torch.ones(4)
+    s.reduce_async(t); s.wait()
+    assert torch.equal(t, torch.ones(4))

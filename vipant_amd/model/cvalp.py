@@ -83,6 +83,8 @@ class CVALP(nn.Module):
 
     # ------------------------------------------------------------------ build (cvalp.py:103-267)
     def _device(self):
+        if not torch.cuda.is_available():       # parameter construction / state-dict surgery can be inspected on a CPU
+            return torch.device("cpu")          # host; forward() on CPU tensors raises (no CPU fallback)
         return torch.device("cuda", self.cfg.rank if self.cfg.rank >= 0 else 0)
 
     def build(self, **kwargs):
