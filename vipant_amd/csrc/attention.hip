@@ -16,6 +16,8 @@
 // applied to the source address.  Backward = two passes with the same structure (dQ per query block with
 // K,V resident; dK,dV per key block with Q,dO resident): 40 % more MFMA work than a single-pass scheme but
 // no float atomics, bitwise reproducible.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -93,8 +95,8 @@ struct MhaArgs {
 };
 
 // ------------------------------------------------------------------------------------------- forward
-template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* kimg = smem;
@@ -108,13 +110,13 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
     const bf16_t* base = p.qkv + row_base * ld + h * 64;
     const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
     const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
-    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, 4, lane);
-    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, 4, lane);
+    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
     __syncthreads();
 
     const int qcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
-    for (int qb = wave; qb * 16 < p.S; qb += 4) {
+    for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
         const int qrow = q < p.S ? q : p.S - 1;
         const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
                 m = fmaxf(m, acc[r]);
             }
             s[kt] = acc;
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // cap the K fragments the scheduler keeps in flight
         }
         m = group_max(m);
         float l = 0.f;
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg, il, u, dt), pf,
                                                                 o[dt], 0, 0, 0);
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (q < p.S) {
             const float inv = __frcp_rn(l);
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs p) {
 }
 
 // ---------------------------------------------------------------------------- backward, pass A: dQ
-template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* kimg = smem;
@@ -186,13 +190,13 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs p) {
     const bf16_t* base = p.qkv + row_base * ld + h * 64;
     const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
     const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
-    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, 4, lane);
-    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, 4, lane);
+    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
     __syncthreads();
 
     const int qcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
-    for (int qb = wave; qb * 16 < p.S; qb += 4) {
+    for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
         const int qrow = q < p.S ? q : p.S - 1;
         const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs p) {
 }
 
 // ------------------------------------------------------------------------ backward, pass B: dK, dV
-template <int NT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* qimg = smem;
@@ -267,9 +271,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs p) {
     const bf16_t* dobase = p.dout + row_base * D + h * 64;
     const int64_t remain_o = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
     const uint32_t lim_o = (uint32_t)(remain_o > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain_o);
-    dma_image(qimg, make_rsrc(base, lim), ld * 2, SP / 8, wave, 4, lane);
-    dma_image(doimg, make_rsrc(dobase, lim_o), D * 2, SP / 8, wave, 4, lane);
-    for (int i = threadIdx.x; i < SP; i += 256) {
+    dma_image(qimg, make_rsrc(base, lim), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(doimg, make_rsrc(dobase, lim_o), D * 2, SP / 8, wave, NW, lane);
+    for (int i = threadIdx.x; i < SP; i += NW * 64) {
         const int64_t stat = ((int64_t)b * p.H + h) * p.S + i;
         slse[i] = i < p.S ? -p.lse[stat] * LOG2E : 0.f;
         sdel[i] = i < p.S ? p.delta[stat] : 0.f;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs p) {
 
     const int kcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
-    for (int kb = wave; kb * 16 < p.S; kb += 4) {
+    for (int kb = wave; kb * 16 < p.S; kb += NW) {
         const int key = kb * 16 + kcol;
         const int krow = key < p.S ? key : p.S - 1;
         const bf16_t* kp = base + (int64_t)krow * ld + D + 8 * g;
@@ -333,37 +337,56 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs p) {
     }
 }
 
-template <int NT, bool CAUSAL>
-int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
+int attn_waves() {
+    static const int nw = getenv("VIPANT_ATTN_WAVES") ? atoi(getenv("VIPANT_ATTN_WAVES")) : 8;
+    return nw == 4 ? 4 : 8;
+}
+
+template <int NT, bool CAUSAL, int NW>
+int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = NT * 16 * 128 * 2;
     static bool configured = false;
     if (!configured) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
-    hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+template <int NT, bool CAUSAL, int NW>
+int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
+    constexpr int lds_a = NT * 16 * 128 * 2;
+    constexpr int lds_b = NT * 16 * 128 * 2 + NT * 16 * 8;
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL, NW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL, NW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        configured = true;
+    }
+    hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds_a, s, a);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((mha_bwd_dkv_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds_b, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
 template <int NT, bool CAUSAL>
+int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
+    // short sequences do not have 8 query blocks to hand out
+    // measured (tools/attn_bench.py, b=512 S=316): forward 380 us with 4 waves vs 431 us with 8
+    return (NT >= 8 && getenv("VIPANT_ATTN_WAVES") && attn_waves() == 8) ? launch_fwd_nw<NT, CAUSAL, 8>(a, s)
+                                                                        : launch_fwd_nw<NT, CAUSAL, 4>(a, s);
+}
+
+template <int NT, bool CAUSAL>
 int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
-    constexpr int lds_a = NT * 16 * 128 * 2;
-    constexpr int lds_b = NT * 16 * 128 * 2 + NT * 16 * 8;
-    static bool configured = false;
-    if (!configured) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
-        configured = true;
-    }
-    hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds_a, s, a);
-    VIPANT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((mha_bwd_dkv_kernel<NT, CAUSAL>), dim3(a.batch * a.H), dim3(256), lds_b, s, a);
-    VIPANT_LAUNCH_CHECK();
-    return VIPANT_OK;
+    // backward: 1184 us with 8 waves vs 1688 us with 4
+    return (NT >= 8 && attn_waves() == 8) ? launch_bwd_nw<NT, CAUSAL, 8>(a, s) : launch_bwd_nw<NT, CAUSAL, 4>(a, s);
 }
 
 template <bool CAUSAL, bool BWD>

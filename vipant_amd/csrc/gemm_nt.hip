@@ -86,6 +86,106 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNT p) {
     }
 }
 
+// Stage the 256x256 accumulator tile through a 64 KiB LDS area and write it out as whole rows (16 B per lane),
+// applying the epilogue on the way.  Uses raw s_barrier + lgkmcnt waits only, so LDS-DMA prefetches in flight survive.
+template <int EPI>
+__device__ __forceinline__ void staged_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], char* stg, int cm0, int cn0, int wm,
+                                                int wn, int frow, int fq, int tid) {
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n4 = cn0 + wn * 64 + j * 16 + fq * 4;
+        bv[j] = (EPI != VIPANT_EPI_DQUICKGELU && p.bias != nullptr && n4 < p.N) ? *(const f32x4*)(p.bias + n4)
+                                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (EPI == VIPANT_EPI_RESIDUAL_F32) {
+        // fp32 tile: 4 rounds of 64 rows x 1 KiB; 16-B chunk index XOR (row & 7)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (wm == (q >> 1)) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = (q & 1) * 4 + ii;
+                    const int row = ii * 16 + frow;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = (wn * 16 + j * 4 + fq) ^ (row & 7);
+                        *(f32x4*)(stg + row * 1024 + ch * 16) = acc[i][j] + bv[j];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int idx = t * 512 + tid;
+                const int row = idx >> 6, ch = idx & 63;
+                const int m = cm0 + q * 64 + row, n = cn0 + ch * 4;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = *(const f32x4*)(stg + row * 1024 + ((ch ^ (row & 7)) << 4));
+                    const int64_t o = (int64_t)m * p.ldc + n;
+                    *(f32x4*)((float*)p.C + o) = v + *(const f32x4*)((const float*)p.aux + o);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // bf16 tile: 2 rounds of 128 rows x 512 B; 16-B chunk index XOR (row & 7)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = i * 16 + frow;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = wn * 64 + j * 16 + fq * 4;
+                        const int ch = (col >> 3) ^ (row & 7);
+                        *(bf16x4*)(stg + row * 512 + ch * 16 + (col & 4) * 2) = f32x4_to_bf16x4(acc[i][j] + bv[j]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int idx = t * 512 + tid;
+                const int row = idx >> 5, ch = idx & 31;
+                const int m = cm0 + h * 128 + row, n = cn0 + ch * 8;
+                if (m < p.M && n < p.N) {
+                    const bf16x8 v = *(const bf16x8*)(stg + row * 512 + ((ch ^ (row & 7)) << 4));
+                    const int64_t o = (int64_t)m * p.ldc + n;
+                    if (EPI == VIPANT_EPI_BF16) {
+                        *(bf16x8*)((bf16_t*)p.C + o) = v;
+                    } else if (EPI == VIPANT_EPI_QUICKGELU) {
+                        *(bf16x8*)((bf16_t*)p.aux + o) = v;
+                        bf16x8 g;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float u = (float)v[e];
+                            g[e] = (bf16_t)(u * fast_sigmoid(1.702f * u));
+                        }
+                        *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    } else {  // VIPANT_EPI_DQUICKGELU
+                        const bf16x8 u8 = *(const bf16x8*)((const bf16_t*)p.aux + o);
+                        bf16x8 d;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float u = (float)u8[e];
+                            const float sg = fast_sigmoid(1.702f * u);
+                            d[e] = (bf16_t)((float)v[e] * (sg * (1.0f + 1.702f * u * (1.0f - sg))));
+                        }
+                        *(bf16x8*)((bf16_t*)p.C + o) = d;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Persistent variant for the large token-major contractions (M >> 256).  Measured on MI355X (tools/gemm_bench.py):
 // the 2-stage main loop alone sustains ~1.1 PFLOP/s, but with K = 768 a tile's epilogue (8-byte partial-line
@@ -135,10 +235,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
         rsA = make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
         rsB = make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
     };
-    auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int stage, int kt) {
+    auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rsA_, const __amdgpu_buffer_rsrc_t& rsB_, int stage, int kt) {
         char* sA = smem + stage * STAGE_BYTES + wave * 4096;
         char* sB = sA + A_BYTES;
-        const uint32_t koff = (uint32_t)kt * (BK * 2);
+        const auto rsA = (p.dbg & 32) ? make_rsrc(p.A, 0x7FFFFFFF) : rsA_;
+        const auto rsB = (p.dbg & 32) ? make_rsrc(p.B, 0x7FFFFFFF) : rsB_;
+        const uint32_t koff = (p.dbg & 32) ? 0u : (uint32_t)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(rsA, sA + i * 1024, voffA[i], koff);
 #pragma unroll
@@ -160,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                       // K-step 0 of this tile has landed in stage 0
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) stage_load(rsA, rsB, (kt + 1) & 1, kt + 1);
+            if (kt + 1 < nk && !(p.dbg & 4)) stage_load(rsA, rsB, (kt + 1) & 1, kt + 1);
             const char* s = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -175,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
-            __syncthreads();
+            if (!(p.dbg & 8)) __syncthreads();
         }
         // both stages are free now: prefetch the next tile's first K-step into stage 0, stage the output through stage 1
         const int cm0 = m0, cn0 = n0;
@@ -184,101 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
             tile_rsrc(next, rsA, rsB, m0, n0);
             stage_load(rsA, rsB, 0, 0);
         }
-        char* stg = smem + STAGE_BYTES;        // 64 KiB staging area
-
-        f32x4 bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n4 = cn0 + wn * 64 + j * 16 + fq * 4;
-            bv[j] = (EPI != VIPANT_EPI_DQUICKGELU && p.bias != nullptr && n4 < p.N) ? *(const f32x4*)(p.bias + n4)
-                                                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (EPI == VIPANT_EPI_RESIDUAL_F32) {
-            // fp32 tile: 4 rounds of 64 rows x 1 KiB; 16-B chunk index XOR (row & 7)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (wm == (q >> 1)) {
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = (q & 1) * 4 + ii;
-                        const int row = ii * 16 + frow;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int ch = (wn * 16 + j * 4 + fq) ^ (row & 7);
-                            *(f32x4*)(stg + row * 1024 + ch * 16) = acc[i][j] + bv[j];
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int idx = t * 512 + tid;
-                    const int row = idx >> 6, ch = idx & 63;
-                    const int m = cm0 + q * 64 + row, n = cn0 + ch * 4;
-                    if (m < p.M && n < p.N) {
-                        const f32x4 v = *(const f32x4*)(stg + row * 1024 + ((ch ^ (row & 7)) << 4));
-                        const int64_t o = (int64_t)m * p.ldc + n;
-                        *(f32x4*)((float*)p.C + o) = v + *(const f32x4*)((const float*)p.aux + o);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        } else {
-            // bf16 tile: 2 rounds of 128 rows x 512 B; 16-B chunk index XOR (row & 7)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (wm == h) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int row = i * 16 + frow;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int col = wn * 64 + j * 16 + fq * 4;
-                            const int ch = (col >> 3) ^ (row & 7);
-                            *(bf16x4*)(stg + row * 512 + ch * 16 + (col & 4) * 2) = f32x4_to_bf16x4(acc[i][j] + bv[j]);
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int idx = t * 512 + tid;
-                    const int row = idx >> 5, ch = idx & 31;
-                    const int m = cm0 + h * 128 + row, n = cn0 + ch * 8;
-                    if (m < p.M && n < p.N) {
-                        const bf16x8 v = *(const bf16x8*)(stg + row * 512 + ((ch ^ (row & 7)) << 4));
-                        const int64_t o = (int64_t)m * p.ldc + n;
-                        if (EPI == VIPANT_EPI_BF16) {
-                            *(bf16x8*)((bf16_t*)p.C + o) = v;
-                        } else if (EPI == VIPANT_EPI_QUICKGELU) {
-                            *(bf16x8*)((bf16_t*)p.aux + o) = v;
-                            bf16x8 g;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float u = (float)v[e];
-                                g[e] = (bf16_t)(u * fast_sigmoid(1.702f * u));
-                            }
-                            *(bf16x8*)((bf16_t*)p.C + o) = g;
-                        } else {  // VIPANT_EPI_DQUICKGELU
-                            const bf16x8 u8 = *(const bf16x8*)((const bf16_t*)p.aux + o);
-                            bf16x8 d;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float u = (float)u8[e];
-                                const float sg = fast_sigmoid(1.702f * u);
-                                d[e] = (bf16_t)((float)v[e] * (sg * (1.0f + 1.702f * u * (1.0f - sg))));
-                            }
-                            *(bf16x8*)((bf16_t*)p.C + o) = d;
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
+        staged_epilogue<EPI>(p, acc, smem + STAGE_BYTES, cm0, cn0, wm, wn, frow, fq, tid);
         tile = next;
     }
 }

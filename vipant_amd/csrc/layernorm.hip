@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* dres, float* dx, int64_t lddx,
                                                      bf16_t* __restrict__ dxb, float* __restrict__ partial, int64_t M) {
     constexpr int D = NV * 256;
-    __shared__ float red[4 * 3 * D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -111,16 +110,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
         }
     }
-    // block reduction of the 4 waves' partial column sums, then one row of partials per block
+    // one row of partial column sums per WAVE (no LDS: keeps 8 workgroups per CU resident for this HBM-bound pass)
+    float* prow = partial + wave * 3 * D;
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-        *(f32x4*)(red + (wv * 3 + 0) * D + (t * 64 + lane) * 4) = dg[t];
-        *(f32x4*)(red + (wv * 3 + 1) * D + (t * 64 + lane) * 4) = db[t];
-        *(f32x4*)(red + (wv * 3 + 2) * D + (t * 64 + lane) * 4) = dsum[t];
+        *(f32x4*)(prow + 0 * D + (t * 64 + lane) * 4) = dg[t];
+        *(f32x4*)(prow + 1 * D + (t * 64 + lane) * 4) = db[t];
+        *(f32x4*)(prow + 2 * D + (t * 64 + lane) * 4) = dsum[t];
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * D; i += 256)
-        partial[(int64_t)blockIdx.x * 3 * D + i] = red[i] + red[3 * D + i] + red[6 * D + i] + red[9 * D + i];
 }
 
 // One workgroup per 64 columns: 4 row-lanes x 64 column-lanes sweep the per-block partials, LDS-reduce the 4 lanes.
@@ -145,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
 
 int ln_blocks(int64_t M) {
     int64_t b = ceil_div(M, 4);
-    return (int)(b > 512 ? 512 : b);
+    return (int)(b > 1024 ? 1024 : b);
 }
 
 }  // namespace
@@ -173,7 +170,7 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
 }
 
 extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
-    return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
+    return (size_t)ln_blocks(M) * 4 * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx,
@@ -207,7 +204,7 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const
 #undef LN_BWD
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(256), 0, s,
-                       (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
+                       (const float*)partial, blocks * 4, (int)D, dgamma, dbeta, dx_colsum, accumulate);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
