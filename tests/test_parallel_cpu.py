@@ -105,3 +105,53 @@ def test_single_process_is_a_no_op():
     t = torch.ones(4)
     s.reduce_async(t); s.wait()
     assert torch.equal(t, torch.ones(4))
+
+
+class _BucketedFn(torch.autograd.Function):
+    """Mimics ops.BackboneFn: the gradients of several parameters are views of one flat buffer whose all-reduce is
+    started INSIDE backward, before autograd has stored (and usually cloned) them into .grad."""
+
+    @staticmethod
+    def forward(ctx, x, sync, w1, w2):
+        ctx.save_for_backward(x, w1, w2)
+        ctx.sync, ctx.params = sync, (w1, w2)
+        return (x @ w1) @ w2
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2 = ctx.saved_tensors
+        flat = torch.empty(w1.numel() + w2.numel())
+        v1, v2 = flat[:w1.numel()].view_as(w1), flat[w1.numel():].view_as(w2)
+        v2.copy_((x @ w1).t() @ g)
+        v1.copy_(x.t() @ (g @ w2.t()))
+        ctx.sync.reduce_async(flat, [v1, v2], list(ctx.params))
+        return None, None, v1, v2
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vipant_amd import parallel
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(8, 5, generator=g)
+        w1 = torch.nn.Parameter(torch.randn(5, 6, generator=g)); w2 = torch.nn.Parameter(torch.randn(6, 4, generator=g))
+        sync = parallel.GradSync()
+        _BucketedFn.apply(x[rank * 4:rank * 4 + 4], sync, w1, w2).sum().backward()
+        sync.wait()
+        if rank == 0:
+            torch.save((w1.grad.clone(), w2.grad.clone()), out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucket_reduced_inside_backward_reaches_param_grad(tmp_path):
+    out = str(tmp_path / "b.pt")
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g1, g2 = torch.load(out)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 5, generator=g)
+    w1 = torch.randn(5, 6, generator=g).requires_grad_(); w2 = torch.randn(6, 4, generator=g).requires_grad_()
+    ((x @ w1) @ w2).sum().backward()
+    assert torch.allclose(g1, w1.grad, atol=1e-5) and torch.allclose(g2, w2.grad, atol=1e-5)

@@ -385,7 +385,7 @@ class BackboneFn(torch.autograd.Function):
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
             if ctx.grad_sync is not None:
-                ctx.grad_sync.reduce_async(lg.flat)
+                ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
             lg = lg_below
         ctx.wts = None
         need = ctx.needs_input_grad

@@ -41,7 +41,12 @@ class _AllGatherRows(torch.autograd.Function):
         x = x.contiguous()
         w = world_size()
         out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather(list(out.chunk(w, dim=0)), x)
+        if x.is_cuda and dist.get_backend() == "gloo":       # gloo cannot gather device tensors: stage through the host
+            host = torch.empty(out.shape, dtype=x.dtype)      # (single-GPU replica tests only; RCCL takes the direct path)
+            dist.all_gather(list(host.chunk(w, dim=0)), x.cpu())
+            out.copy_(host)
+        else:
+            dist.all_gather(list(out.chunk(w, dim=0)), x)
         ctx.b = x.shape[0]
         return out
 
@@ -65,6 +70,7 @@ class GradSync:
         self.group = group
         self.handles: List = []
         self.buffers: List[torch.Tensor] = []
+        self.pairs: List = []
         self.stream: Optional[torch.cuda.Stream] = None
 
     def _comm_stream(self, device):
@@ -72,9 +78,15 @@ class GradSync:
             self.stream = torch.cuda.Stream(device=device)
         return self.stream
 
-    def reduce_async(self, flat: torch.Tensor):
+    def reduce_async(self, flat: torch.Tensor, views=None, params=None):
+        """Start the SUM all-reduce of one bucket.  `views` / `params` (optional, same length) name the slices of
+        `flat` that are the gradients of `params`: autograd usually CLONES a gradient it is handed while other
+        references to it exist, so after the reduction `wait()` copies the reduced slices over whatever tensor ended
+        up in `param.grad`."""
         if world_size() == 1:
             return
+        if views is not None:
+            self.pairs.extend(zip(params, views))
         if flat.is_cuda:
             comm = self._comm_stream(flat.device)
             comm.wait_stream(torch.cuda.current_stream(flat.device))    # bucket is complete on the compute stream
@@ -103,4 +115,7 @@ class GradSync:
             h.wait()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
-        self.handles, self.buffers = [], []
+        for p, v in self.pairs:
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                p.grad.copy_(v)
+        self.handles, self.buffers, self.pairs = [], [], []
