@@ -56,10 +56,11 @@ int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
 /* Weight-gradient contraction (autograd of nn.Linear weight): C[P,Q] (+)= A[M,P]^T . B[M,Q], reduction
  * over the token dimension M (both operands M-major).  Q % 4 == 0 (P arbitrary).  fp32 output;
  * accumulate != 0 adds into C.  Deterministic split over M through `workspace`
- * (vipant_gemm_tn_workspace_bytes). */
+ * (vipant_gemm_tn_workspace_bytes).  a_colsum (optional fp32 [P]) (+)= sum_m A[m, p]: the bias gradient of the
+ * same Linear, taken from the A tiles while they sit in LDS (no extra pass over dY). */
 size_t vipant_gemm_tn_workspace_bytes(int64_t M, int64_t P, int64_t Q);
 int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc,
-                       int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace,
+                       int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum, void* workspace,
                        size_t workspace_bytes, void* stream);
 
 /* Column sums over tokens (bias gradients): out[N] (+)= sum_m X[m, n]; X bf16 [M, N]. */

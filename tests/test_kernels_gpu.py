@@ -121,8 +121,14 @@ def test_gemm_tn(ops, M, P, Q):
     ops.gemm_tn(a, b, c)
     assert_close(c, ref, 1e-4, 2e-3 * math.sqrt(M), "tn")
     c2 = torch.full((P, Q), 1.5, device=DEV)
-    ops.gemm_tn(a, b, c2, accumulate=True)
+    cs = torch.full((P,), 0.25, device=DEV)
+    ops.gemm_tn(a, b, c2, accumulate=True, a_colsum=cs)
     assert_close(c2, ref + 1.5, 1e-4, 2e-3 * math.sqrt(M), "tn accumulate")
+    assert_close(cs, a.float().sum(0) + 0.25, 1e-5, 1e-3 * math.sqrt(M), "tn fused column sums (accumulate)")
+    cs2 = torch.empty(P, device=DEV)
+    ops.gemm_tn(a, b, c, a_colsum=cs2)
+    assert_close(cs2, a.float().sum(0), 1e-5, 1e-3 * math.sqrt(M), "tn fused column sums")
+    assert_close(c, ref, 1e-4, 2e-3 * math.sqrt(M), "tn (with column sums)")
 
 
 def test_gemm_tn_layout(ops):

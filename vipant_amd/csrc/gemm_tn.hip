@@ -22,6 +22,7 @@ struct GemmTN {
     int M, P, Q;
     int splits, kt_per_split;
     int direct;   // 1: write straight into C (single split, no accumulate)
+    float* colsum;   // optional [splits][ntp*256]: per-split column sums of A (bias gradient of the same Linear)
 };
 
 __device__ __forceinline__ int tn_swz(int m) { return ((m & 3) | (((m >> 3) & 1) << 2)) << 1; }
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Column sums of A over the token dimension ride along: the A tile is in LDS anyway.  Thread t owns column
+    // (t & 255) and the rows of half (t >> 8) of every K-tile; only the workgroups of the first Q tile do it.
+    const bool do_colsum = p.colsum != nullptr && tq == 0;
+    const int cs_col = tid & 255, cs_half = tid >> 8;
+    float cs_acc = 0.f;
     if (nk > 0) {
         stage_load(0, 0);
         __syncthreads();
@@ -112,6 +118,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
             if (kt + 1 < nk) stage_load(cur ^ 1, kt + 1);
             const char* sA = smem + cur * STAGE_BYTES;
             const char* sB = sA + OP_BYTES;
+            if (do_colsum) {
+#pragma unroll 8
+                for (int mm = 0; mm < 32; ++mm) {
+                    const int m = cs_half * 32 + mm;
+                    cs_acc += (float)*(const bf16_t*)(sA + m * 512 + (((cs_col >> 3) ^ tn_swz(m)) << 4) + (cs_col & 7) * 2);
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 fq[4];
@@ -130,6 +143,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
         }
     }
 
+    if (do_colsum) {      // all LDS reads of the loop are behind its last barrier: reuse the front of the buffer
+        float* red = (float*)smem;
+        red[tid] = cs_acc;
+        __syncthreads();
+        if (tid < 256) p.colsum[(int64_t)split * (ntp * TP) + p0 + tid] = red[tid] + red[tid + 256];
+    }
     // lane holds C[p = p0 + wp*128 + i*16 + (lane&15)][q = q0 + wq*64 + j*16 + (lane>>4)*4 + 0..3]
     const int frow = lane & 15;
     if (p.direct) {
@@ -173,6 +192,14 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, 
     }
 }
 
+__global__ void gemm_tn_colsum_reduce_kernel(const float* part, float* out, int P, int stride, int splits, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
 void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
     const int64_t nk = ceil_div(M, BK);
@@ -189,12 +216,13 @@ void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
 extern "C" size_t vipant_gemm_tn_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
     int splits, per;
     plan(M, P, Q, &splits, &per);
-    return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float);
+    return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float) +
+           (size_t)splits * (size_t)ceil_div(P, TP) * TP * sizeof(float);
 }
 
 extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C,
-                                  int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     VIPANT_REQUIRE(M > 0 && P > 0 && Q > 0, VIPANT_EBADSHAPE, "gemm_tn: empty problem");
     VIPANT_REQUIRE(Q % 4 == 0, VIPANT_EBADSHAPE, "gemm_tn: need Q%%4==0 (P=%ld Q=%ld)",
                    (long)P, (long)Q);
@@ -208,7 +236,7 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
                    "gemm_tn: per-split byte range exceeds 4 GiB");
     const size_t need = vipant_gemm_tn_workspace_bytes(M, P, Q);
     const int direct = (splits == 1 && !accumulate) ? 1 : 0;
-    if (!direct)
+    if (!direct || a_colsum != nullptr)
         VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= need, VIPANT_ENOWORKSPACE,
                        "gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
     static bool configured = false;
@@ -219,8 +247,10 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
+    const size_t slab_bytes = (size_t)splits * (size_t)tiles * TP * TQ * sizeof(float);
+    float* cs_part = a_colsum != nullptr ? (float*)((char*)workspace + slab_bytes) : nullptr;
     GemmTN p{(const bf16_t*)A, (const bf16_t*)B, direct ? C : (float*)workspace, lda, ldb, direct ? ldc : TQ,
-             (int)M, (int)P, (int)Q, splits, per, direct};
+             (int)M, (int)P, (int)Q, splits, per, direct, cs_part};
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 2 * STAGE_BYTES, s, p);
     VIPANT_LAUNCH_CHECK();
     if (!direct) {
@@ -229,6 +259,11 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, C, ldc,
                            (int)P, (int)Q, splits, accumulate);
+        VIPANT_LAUNCH_CHECK();
+    }
+    if (a_colsum != nullptr) {
+        hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s,
+                           (const float*)cs_part, a_colsum, (int)P, (int)(ceil_div(P, TP) * TP), splits, accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;

@@ -284,7 +284,7 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     }
     if (dx2 != nullptr) {
         const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + row0), w.Bp, (const uint16_t*)w.x1cat, 3 * E, dx2, E, B,
-                                         nrows, E, 0, w.tn_ws, w.tn_bytes, stream);
+                                         nrows, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
     }
     return VIPANT_OK;

@@ -85,8 +85,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux
     return c
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
-    """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out)."""
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False, a_colsum=None):
+    """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out); a_colsum (fp32 [P], optional) (+)= column sums of a."""
     _need(a, BF16, "gemm_tn.a"); _need(b, BF16, "gemm_tn.b"); _need(c, F32, "gemm_tn.c")
     M, P = a.shape
     Q = b.shape[1]
@@ -94,7 +94,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool 
     nbytes = query("vipant_gemm_tn_workspace_bytes", M, P, Q)
     ws = scratch("gemm_tn", nbytes, a.device)
     call("vipant_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), M, P, Q,
-         int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+         int(accumulate), _ptr(a_colsum), ws.data_ptr(), ws.numel(), _stream())
     return c
 
 
@@ -357,8 +357,7 @@ class BackboneFn(torch.autograd.Function):
             # c_fc
             dh2 = torch.empty((M, D), dtype=BF16, device=dev)
             gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
-            gemm_tn(du, h2, d_wfc)
-            colsum(du, d_bfc)
+            gemm_tn(du, h2, d_wfc, a_colsum=d_bfc)
             del du
             # ln_2 (+ residual gradient); its output dx1 is also d(out_proj output): column sum = d out_proj.bias
             dx1 = torch.empty((M, D), dtype=F32, device=dev)
@@ -374,8 +373,7 @@ class BackboneFn(torch.autograd.Function):
             # in_proj
             dh1 = do
             gemm_nt(dqkv, wqkv_t, dh1, epi=EPI_BF16)
-            gemm_tn(dqkv, h1, d_wqkv)
-            colsum(dqkv, d_bqkv)
+            gemm_tn(dqkv, h1, d_wqkv, a_colsum=d_bqkv)
             del dqkv
             # ln_1 (+ residual gradient), in place on the stream buffers; the produced dx is d(c_proj output) of the
             # block below: its column sum is that block's d c_proj.bias
