@@ -110,31 +110,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
         }
     }
-    // one row of partial column sums per WAVE (no LDS: keeps 8 workgroups per CU resident for this HBM-bound pass)
-    float* prow = partial + wave * 3 * D;
+    // block reduction of the 4 waves' column sums, one quantity at a time through a [4][D] LDS buffer (12 KiB at
+    // D = 768: does not limit residency), then one row of partials per BLOCK
+    __shared__ float red[4 * D];
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        *(f32x4*)(prow + 0 * D + (t * 64 + lane) * 4) = dg[t];
-        *(f32x4*)(prow + 1 * D + (t * 64 + lane) * 4) = db[t];
-        *(f32x4*)(prow + 2 * D + (t * 64 + lane) * 4) = dsum[t];
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+            *(f32x4*)(red + wv * D + (t * 64 + lane) * 4) = which == 0 ? dg[t] : (which == 1 ? db[t] : dsum[t]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += 256)
+            partial[((int64_t)blockIdx.x * 3 + which) * D + i] = red[i] + red[D + i] + red[2 * D + i] + red[3 * D + i];
+        __syncthreads();
     }
 }
 
-// One workgroup per 64 columns: 4 row-lanes x 64 column-lanes sweep the per-block partials, LDS-reduce the 4 lanes.
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                                              float* dgamma, float* dbeta, float* dxcolsum,
-                                                              int accumulate) {
-    __shared__ float red[4][64];
+// One workgroup per 64 columns: 16 row-lanes x 64 column-lanes sweep the per-block partials, LDS-reduce the lanes.
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                               float* dgamma, float* dbeta, float* dxcolsum,
+                                                               int accumulate) {
+    __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;          // index into the [3 * D] (dgamma | dbeta | colsum dx) vector
     const int lim = dxcolsum != nullptr ? 3 * D : 2 * D;
     float s = 0.f;
     if (i < lim)
-        for (int b = ty; b < nblocks; b += 4) s += partial[(int64_t)b * 3 * D + i];
+        for (int b = ty; b < nblocks; b += 16) s += partial[(int64_t)b * 3 * D + i];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && i < lim) {
-        s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][tx];
         float* dst = i < D ? dgamma + i : (i < 2 * D ? dbeta + (i - D) : dxcolsum + (i - 2 * D));
         *dst = accumulate ? *dst + s : s;
     }
@@ -170,7 +177,7 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
 }
 
 extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
-    return (size_t)ln_blocks(M) * 4 * 3 * (size_t)D * sizeof(float);
+    return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
 extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx,
@@ -203,8 +210,8 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const
     }
 #undef LN_BWD
     VIPANT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(256), 0, s,
-                       (const float*)partial, blocks * 4, (int)D, dgamma, dbeta, dx_colsum, accumulate);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(1024), 0, s,
+                       (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
