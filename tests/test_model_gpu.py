@@ -220,3 +220,63 @@ def test_trainer_step_matches_oracle_lars():
             assert err <= 1e-6 + 1e-5 * float(p_ref.abs().max()), (k, step, err)
         step += 1
     assert step == 2
+
+
+def test_at_step_with_frozen_text_tower():
+    """AT fine-tuning layout (bash/run_bimodal_at.sh): trainable audio head + frozen causal CLIP text tower +
+    VALCELossHead(al).  One VALMonitor step against the CPU oracle on the same weights / batch (loss), plus the
+    trainer bookkeeping (which parameters moved)."""
+    from oracle import ref_cpu as R
+    from vipant_amd.config import compose
+    from vipant_amd.monitor import VALMonitor
+    ov = ("+running=trimodal monitor=VALMonitor worker=CVALP mode=dp eval=False num_gpus=1 +model/image=vit_val "
+          "+model/audio=vit_val +model/text=transformer_val +model/loss=ce_val +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True running.imagine=False model.loss.va=False "
+          "model.image.encoder.layers=2 model.text.encoder.layers=2 running.audio.max_len=256 running.audio.num_mel_bins=64 "
+          "running.batch_size=8 running.epochs=2 running.synthetic_steps=1 running.save_epoch=False optimizer.warmup_epoch=1").split()
+    cfg = compose(ov)
+    cfg.rank = 0
+    torch.manual_seed(cfg.seed)
+    mon = VALMonitor(cfg, lambda *_: None, torch.device(DEV))
+    assert mon.model.image_head is None and mon.model.text_head is not None
+    batch = next(iter(mon.dataloader))
+    images, audios, text, _, _ = mon.make_batch(batch)
+    assert list(images.shape[1:]) == [1, 1, 1] and text.dtype == torch.int64 and audios.shape[1:] == (1, 256, 64)
+    asd = {k: v.detach().cpu().clone() for k, v in mon.model.audio_head.state_dict().items()}
+    tsd = {k: v.detach().cpu().clone() for k, v in mon.model.text_head.state_dict().items()}
+    ls = mon.model.loss_head.loss_head_al.logit_scale.detach().cpu().clone()
+    from vipant_amd.module import adjust_learning_rate
+    adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, 1)
+    before = {k: v.detach().clone() for k, v in mon.model.named_parameters()}
+    loss = mon.step(images, audios, text)
+    stride, S, pr = R.vit_position_resolution([256, 64], 32, [16, 24])
+    ref = R.cvalp_forward(images.cpu(), audios.cpu(), text.cpu(), audio_sd=asd, text_sd=tsd, loss="valce",
+                          scales={"al": ls}, loss_flags=dict(va=False, lv=False, al=True),
+                          audio_cfg=dict(width=768, layers=2, stride=stride, position_resolution=pr),
+                          text_cfg=dict(width=512, layers=2, ctx_len=77))
+    assert abs(float(loss.detach()) - float(ref)) < 5e-3, (float(loss.detach()), float(ref))
+    moved = {k for k, v in mon.model.named_parameters() if not torch.equal(v.detach(), before[k])}
+    assert all(k.startswith(("audio_head.", "loss_head.")) for k in moved) and len(moved) > 30
+    assert "al" in mon.model.report(nstep=1)
+
+
+def test_train_entry_runs_both_launch_scripts(tmp_path, monkeypatch):
+    """train.py with the override strings of run_bimodal_va.sh / run_bimodal_at.sh (shrunk model, synthetic batches):
+    two optimisation steps each, checkpoint written in the reference's 4-tuple format."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    import train as entry
+    common = (f"alias_root={tmp_path} model_name=t port=1 num_gpus=1 mode=dp num_proc=2 eval=False verbose=False "
+              "+model/image=vit_val +model/audio=vit_val +optimizer=standard +running/audio=default "
+              "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] optimizer.warmup=False "
+              "running.audio.norms=[-4.93839311,5.75751113] model.image.encoder.layers=1 running.audio.max_len=256 "
+              "running.audio.num_mel_bins=64 running.synthetic_steps=2 running.epochs=1 running.peep_rate=1").split()
+    va = ["+running=bimodal", "worker=CVALP", "+model/text=dummy", "+model/loss=ce", "running.batch_size=4"] + common
+    entry.train(va)
+    at = ["+running=trimodal", "monitor=VALMonitor", "worker=CVALP", "+model/text=transformer_val", "+model/loss=ce_val",
+          "running.siamese.alive=True", "running.imagine=False", "model.loss.va=False", "running.batch_size=4",
+          "model.text.encoder.layers=1", "model_file=notafile", "+running.rnd_cap=True"] + common
+    entry.train(at)
+    ck = torch.load(tmp_path / "t" / "00000002.pth", weights_only=False)
+    assert len(ck["model"]) == 4 and "encoder.resblocks.0.attn.in_proj_weight" in ck["model"][1]
+    assert "loss_head_al.logit_scale" in ck["model"][3] and ck["cfg"]["worker"] == "CVALP"
