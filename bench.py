@@ -31,6 +31,17 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
     return layers * S * (24 * width * width + 4 * S * width) + 2 * P * kpatch * width + 2 * width * embed
 
 
+def pmc_traffic(M, N, K):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, see that file for the commands and the calibration); None for any other shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(f"gemm_nt_persistent_kernel<3> M={M} N={N} K={K}")
+        return None if k is None else k["fetch_bytes"] + k["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,7 +52,7 @@ def parse():
     ap.add_argument("--mels", type=int, default=128)
     ap.add_argument("--layers", type=int, default=L)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
 
 
@@ -165,9 +176,10 @@ def main():
         "loss": round(float(loss.detach()), 4),
         "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_QUICKGELU> (c_fc forward, M=%d N=%d K=%d)" % (Mrows, 4 * D, D),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel<3> (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (Mrows, 4 * D, D),
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * D, D),
+                     "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * D + 4 * D * D + 2 * Mrows * 4 * D),
                      "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
     }
     if rank == 0:
