@@ -29,6 +29,13 @@ constexpr float C2 = SCALE * LOG2E;
 __device__ __forceinline__ int img_swz(int r) { return ((r >> 1) & 3) << 1; }
 
 // Fill a [rows8*8 x 64] bf16 LDS image from `rows8*8` consecutive rows (stride ld_bytes) of a buffer.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
+    // descriptor inputs made provably wave-uniform, otherwise hipcc wraps every buffer op in a waterfall loop
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return make_rsrc((const void*)(((uint64_t)hi << 32) | lo), (uint32_t)__builtin_amdgcn_readfirstlane(bytes));
+}
+
 __device__ __forceinline__ void dma_image(char* lds, __amdgpu_buffer_rsrc_t rs, uint32_t ld_bytes, int rows8,
                                           int wave, int nwaves, int lane) {
     for (int blk = wave; blk < rows8; blk += nwaves) {
@@ -95,8 +102,8 @@ struct MhaArgs {
 };
 
 // ------------------------------------------------------------------------------------------- forward
-template <int NT, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW, int EDGE>
+__global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* kimg = smem;
@@ -110,18 +117,26 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs p) {
     const bf16_t* base = p.qkv + row_base * ld + h * 64;
     const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
     const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
-    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
-    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(kimg, uniform_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(vimg, uniform_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
     __syncthreads();
 
     const int qcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
+    // The query fragments of a block come straight from HBM: fetch block i+1's while block i computes (the first
+    // fetch flies under the K/V DMA), otherwise every block starts with an exposed global-load latency.
+    auto load_q = [&](int qb, bf16x8& f0, bf16x8& f1) {
+        const int qq = qb * 16 + qcol;
+        const bf16_t* qp = base + (int64_t)(qq < p.S ? qq : p.S - 1) * ld + 8 * g;
+        f0 = *(const bf16x8*)qp;
+        f1 = *(const bf16x8*)(qp + 32);
+    };
+    bf16x8 qn0, qn1;
+    load_q(wave, qn0, qn1);
     for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
-        const int qrow = q < p.S ? q : p.S - 1;
-        const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
-        const bf16x8 qf0 = *(const bf16x8*)qp;
-        const bf16x8 qf1 = *(const bf16x8*)(qp + 32);
+        const bf16x8 qf0 = qn0, qf1 = qn1;
+        if ((qb + NW) * 16 < p.S) load_q(qb + NW, qn0, qn1);
 
         f32x4 s[NT];
         float m = -INFINITY;
@@ -130,12 +145,17 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs p) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, acc, 0, 0, 0);
+            // masking code exists only for the last EDGE key tiles (compile-time): with NT chosen as the smallest
+            // even tile count that covers S, at most the last two tiles can hold keys >= S; the causal (text) variant
+            // masks everywhere.
+            if (CAUSAL || kt >= NT - EDGE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + g * 4 + r;
-                if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
-                m = fmaxf(m, acc[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + g * 4 + r;
+                    if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
+                }
             }
+            m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
             s[kt] = acc;
             if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // cap the K fragments the scheduler keeps in flight
         }
@@ -175,8 +195,8 @@ __global__ __launch_bounds__(NW * 64) void mha_fwd_kernel(MhaArgs p) {
 }
 
 // ---------------------------------------------------------------------------- backward, pass A: dQ
-template <int NT, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW, int EDGE>
+__global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dq_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* kimg = smem;
@@ -190,29 +210,40 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs p) {
     const bf16_t* base = p.qkv + row_base * ld + h * 64;
     const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
     const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
-    dma_image(kimg, make_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
-    dma_image(vimg, make_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(kimg, uniform_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(vimg, uniform_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0), ld * 2, SP / 8, wave, NW, lane);
     __syncthreads();
 
     const int qcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
+    struct QBlock { bf16x8 q0, q1, do0, do1, o0, o1; float lse; };
+    auto load_blk = [&](int qb, QBlock& t) {
+        const int qq = qb * 16 + qcol;
+        const int qrow = qq < p.S ? qq : p.S - 1;
+        const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
+        t.q0 = *(const bf16x8*)qp;
+        t.q1 = *(const bf16x8*)(qp + 32);
+        const int64_t orow = (row_base + qrow) * D + h * 64 + 8 * g;
+        t.do0 = *(const bf16x8*)(p.dout + orow);
+        t.do1 = *(const bf16x8*)(p.dout + orow + 32);
+        t.o0 = *(const bf16x8*)(p.out + orow);
+        t.o1 = *(const bf16x8*)(p.out + orow + 32);
+        t.lse = p.lse[((int64_t)b * p.H + h) * p.S + qrow];
+    };
+    QBlock nxt;
+    load_blk(wave, nxt);
     for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
         const int qrow = q < p.S ? q : p.S - 1;
-        const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
-        const bf16x8 qf0 = *(const bf16x8*)qp;
-        const bf16x8 qf1 = *(const bf16x8*)(qp + 32);
-        const int64_t orow = (row_base + qrow) * D + h * 64 + 8 * g;
-        const bf16x8 do0 = *(const bf16x8*)(p.dout + orow);
-        const bf16x8 do1 = *(const bf16x8*)(p.dout + orow + 32);
-        const bf16x8 o0 = *(const bf16x8*)(p.out + orow);
-        const bf16x8 o1 = *(const bf16x8*)(p.out + orow + 32);
+        const QBlock cur = nxt;
+        if ((qb + NW) * 16 < p.S) load_blk(qb + NW, nxt);
+        const bf16x8 qf0 = cur.q0, qf1 = cur.q1, do0 = cur.do0, do1 = cur.do1, o0 = cur.o0, o1 = cur.o1;
         float dl = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dl += (float)do0[e] * (float)o0[e] + (float)do1[e] * (float)o1[e];
         dl = group_sum(dl);
         const int64_t stat = ((int64_t)b * p.H + h) * p.S + qrow;
-        const float nlse = -p.lse[stat] * LOG2E;
+        const float nlse = -cur.lse * LOG2E;
         if (g == 0 && q < p.S) p.delta[stat] = dl;
 
         f32x4 dq[4];
@@ -231,9 +262,11 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs p) {
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 1), do1, dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + g * 4 + r;
-                    const bool dead = key >= p.S || (CAUSAL && key > q);
-                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(sa[r] * C2 + nlse);
+                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nlse);
+                    if (CAUSAL || kt >= NT - EDGE) {         // compile-time for the non-causal towers
+                        const int key = kt * 16 + g * 4 + r;
+                        if (key >= p.S || (CAUSAL && key > q)) pr = 0.f;
+                    }
                     ds2[t][r] = pr * (dp[r] - dl) * SCALE;
                 }
             }
@@ -251,8 +284,8 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dq_kernel(MhaArgs p) {
 }
 
 // ------------------------------------------------------------------------ backward, pass B: dK, dV
-template <int NT, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs p) {
+template <int NT, bool CAUSAL, int NW, int EDGE>
+__global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
     char* qimg = smem;
@@ -271,8 +304,8 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs p) {
     const bf16_t* dobase = p.dout + row_base * D + h * 64;
     const int64_t remain_o = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
     const uint32_t lim_o = (uint32_t)(remain_o > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain_o);
-    dma_image(qimg, make_rsrc(base, lim), ld * 2, SP / 8, wave, NW, lane);
-    dma_image(doimg, make_rsrc(dobase, lim_o), D * 2, SP / 8, wave, NW, lane);
+    dma_image(qimg, uniform_rsrc(base, lim), ld * 2, SP / 8, wave, NW, lane);
+    dma_image(doimg, uniform_rsrc(dobase, lim_o), D * 2, SP / 8, wave, NW, lane);
     for (int i = threadIdx.x; i < SP; i += NW * 64) {
         const int64_t stat = ((int64_t)b * p.H + h) * p.S + i;
         slse[i] = i < p.S ? -p.lse[stat] * LOG2E : 0.f;
@@ -282,14 +315,22 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs p) {
 
     const int kcol = lane & 15, g = lane >> 4;
     const ImgLane il = img_lane(lane);
+    struct KBlock { bf16x8 k0, k1, v0, v1; };
+    auto load_kv = [&](int kb, KBlock& t) {
+        const int kk = kb * 16 + kcol;
+        const bf16_t* kp = base + (int64_t)(kk < p.S ? kk : p.S - 1) * ld + D + 8 * g;
+        t.k0 = *(const bf16x8*)kp;
+        t.k1 = *(const bf16x8*)(kp + 32);
+        t.v0 = *(const bf16x8*)(kp + D);
+        t.v1 = *(const bf16x8*)(kp + D + 32);
+    };
+    KBlock knxt;
+    load_kv(wave, knxt);
     for (int kb = wave; kb * 16 < p.S; kb += NW) {
         const int key = kb * 16 + kcol;
-        const int krow = key < p.S ? key : p.S - 1;
-        const bf16_t* kp = base + (int64_t)krow * ld + D + 8 * g;
-        const bf16x8 kf0 = *(const bf16x8*)kp;
-        const bf16x8 kf1 = *(const bf16x8*)(kp + 32);
-        const bf16x8 vf0 = *(const bf16x8*)(kp + D);
-        const bf16x8 vf1 = *(const bf16x8*)(kp + D + 32);
+        const KBlock kcur = knxt;
+        if ((kb + NW) * 16 < p.S) load_kv(kb + NW, knxt);
+        const bf16x8 kf0 = kcur.k0, kf1 = kcur.k1, vf0 = kcur.v0, vf1 = kcur.v1;
 
         f32x4 dk[4], dv[4];
 #pragma unroll
@@ -309,9 +350,11 @@ __global__ __launch_bounds__(NW * 64) void mha_bwd_dkv_kernel(MhaArgs p) {
                 const f32x4 dl = *(const f32x4*)(sdel + qt * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 16 + g * 4 + r;
-                    const bool dead = q >= p.S || (CAUSAL && key > q);
-                    const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(sa[r] * C2 + nl[r]);
+                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nl[r]);
+                    if (CAUSAL || qt >= NT - EDGE) {
+                        const int q = qt * 16 + g * 4 + r;
+                        if (q >= p.S || (CAUSAL && key > q)) pr = 0.f;
+                    }
                     p2[t][r] = pr;
                     ds2[t][r] = pr * (dp[r] - dl[r]) * SCALE;
                 }
@@ -342,51 +385,53 @@ int attn_waves() {
     return nw == 4 ? 4 : 8;
 }
 
-template <int NT, bool CAUSAL, int NW>
+template <int NT, bool CAUSAL, int NW, int EDGE>
 int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = NT * 16 * 128 * 2;
     static bool configured = false;
     if (!configured) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
-    hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
-template <int NT, bool CAUSAL, int NW>
+template <int NT, bool CAUSAL, int NW, int EDGE>
 int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
     constexpr int lds_a = NT * 16 * 128 * 2;
     constexpr int lds_b = NT * 16 * 128 * 2 + NT * 16 * 8;
     static bool configured = false;
     if (!configured) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL, NW>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL, NW>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         configured = true;
     }
-    hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds_a, s, a);
+    hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds_a, s, a);
     VIPANT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((mha_bwd_dkv_kernel<NT, CAUSAL, NW>), dim3(a.batch * a.H), dim3(NW * 64), lds_b, s, a);
+    hipLaunchKernelGGL((mha_bwd_dkv_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds_b, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
+// EDGE = 2 when only the last two key tiles can be partial (S > (NT - 2) * 16), else every tile carries mask code.
 template <int NT, bool CAUSAL>
 int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
-    // short sequences do not have 8 query blocks to hand out
-    // measured (tools/attn_bench.py, b=512 S=316): forward 380 us with 4 waves vs 431 us with 8
-    return (NT >= 8 && getenv("VIPANT_ATTN_WAVES") && attn_waves() == 8) ? launch_fwd_nw<NT, CAUSAL, 8>(a, s)
-                                                                        : launch_fwd_nw<NT, CAUSAL, 4>(a, s);
+    // measured (tools/attn_bench.py, b=512 S=316): forward is faster with 4 waves, backward with 8
+    const bool tight = a.S > (NT - 2) * 16;
+    return tight ? launch_fwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_fwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
 
 template <int NT, bool CAUSAL>
 int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
-    // backward: 1184 us with 8 waves vs 1688 us with 4
-    return (NT >= 8 && attn_waves() == 8) ? launch_bwd_nw<NT, CAUSAL, 8>(a, s) : launch_bwd_nw<NT, CAUSAL, 4>(a, s);
+    const bool tight = a.S > (NT - 2) * 16;
+    if (NT >= 8 && attn_waves() == 8)
+        return tight ? launch_bwd_nw<NT, CAUSAL, 8, 2>(a, s) : launch_bwd_nw<NT, CAUSAL, 8, NT>(a, s);
+    return tight ? launch_bwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_bwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
 
 template <bool CAUSAL, bool BWD>
