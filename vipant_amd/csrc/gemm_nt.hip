@@ -264,18 +264,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk && !(p.dbg & 4)) stage_load(rsA, rsB, (kt + 1) & 1, kt + 1);
             const char* s = smem + (kt & 1) * STAGE_BYTES;
+            // Fragment pipeline: left alone, hipcc sinks every A-fragment read to just before its 4 MFMAs and waits
+            // lgkmcnt(0) there (minimal registers, LDS latency exposed per MFMA group).  Keep the A reads two groups
+            // ahead in a 3-deep register ring and pin the order with sched_barrier between groups.
+            bf16x8 b[2][4], aq[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[8], b[4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(s + offB[ks] + j * 2048);
+                for (int j = 0; j < 4; ++j) b[ks][j] = *(const bf16x8*)(s + offB[ks] + j * 2048);
+            aq[0] = *(const bf16x8*)(s + offA[0]);
+            aq[1] = *(const bf16x8*)(s + offA[0] + 2048);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(s + offA[ks] + i * 2048);
+            for (int t = 0; t < 16; ++t) {
+                const int ks = t >> 3, i = t & 7;
+                if (t + 2 < 16) aq[(t + 2) % 3] = *(const bf16x8*)(s + offA[(t + 2) >> 3] + ((t + 2) & 7) * 2048);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][j], aq[t % 3], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (!(p.dbg & 8)) __syncthreads();
         }
