@@ -100,6 +100,27 @@ def test_gemm_nt_fused_epilogues(ops):
     assert_close(out, ref, 1e-2, 2e-2, "dquickgelu")
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 2304, 768), (5000, 200, 64), (4096, 3072, 128), (6001, 776, 1024)])
+def test_gemm_nt_short_k_large_m(ops, M, N, K):
+    """Short K, many row tiles per workgroup (the persistent tile walk): ragged M / N tails and all three staged epilogues."""
+    a = rnd(M, K, seed=21, dtype=torch.bfloat16); b = rnd(N, K, seed=22, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=23)
+    pre = a.float() @ b.float().t() + bias
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, c, bias=bias, epi=ops.EPI_BF16)
+    assert_close(c, pre, 1e-2, 2e-2, "bf16 epilogue")
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); g = torch.empty_like(u)
+    ops.gemm_nt(a, b, g, bias=bias, aux=u, epi=ops.EPI_QUICKGELU)
+    assert_close(u, pre, 1e-2, 2e-2, "quickgelu.u")
+    assert_close(g, pre * torch.sigmoid(1.702 * pre), 1e-2, 2e-2, "quickgelu.g")
+    uu = rnd(M, N, seed=24, dtype=torch.bfloat16, scale=2.0)
+    acc = a.float() @ b.float().t()
+    sg = torch.sigmoid(1.702 * uu.float())
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, out, aux=uu, epi=ops.EPI_DQUICKGELU)
+    assert_close(out, acc * (sg * (1 + 1.702 * uu.float() * (1 - sg))), 1e-2, 2e-2, "dquickgelu")
+
+
 def test_gemm_nt_strided_rows(ops):
     """cls-row read-out: A rows taken with a large row stride."""
     S, D = 31, 768

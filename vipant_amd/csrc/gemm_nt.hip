@@ -235,12 +235,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
         rsA = make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
         rsB = make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
     };
-    auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rsA_, const __amdgpu_buffer_rsrc_t& rsB_, int stage, int kt) {
+    auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int stage, int kt) {
         char* sA = smem + stage * STAGE_BYTES + wave * 4096;
         char* sB = sA + A_BYTES;
-        const auto rsA = (p.dbg & 32) ? make_rsrc(p.A, 0x7FFFFFFF) : rsA_;
-        const auto rsB = (p.dbg & 32) ? make_rsrc(p.B, 0x7FFFFFFF) : rsB_;
-        const uint32_t koff = (p.dbg & 32) ? 0u : (uint32_t)kt * (BK * 2);
+        const uint32_t koff = (uint32_t)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(rsA, sA + i * 1024, voffA[i], koff);
 #pragma unroll

@@ -125,18 +125,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
                     cs_acc += (float)*(const bf16_t*)(sA + m * 512 + (((cs_col >> 3) ^ tn_swz(m)) << 4) + (cs_col & 7) * 2);
                 }
             }
+            // Explicit fragment pipeline (same as the NT kernel): the B fragments of the whole K-tile first, the A
+            // fragments in a 3-deep register ring two MFMA groups ahead of their use.
+            bf16x8 fq[2][4], fp[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fq[4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fq[j] = frag(sB, ks, wq * 4 + j);
+                for (int j = 0; j < 4; ++j) fq[ks][j] = frag(sB, ks, wq * 4 + j);
+            fp[0] = frag(sA, 0, wp * 8 + 0);
+            fp[1] = frag(sA, 0, wp * 8 + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bf16x8 fp = frag(sA, ks, wp * 8 + i);
+            for (int t = 0; t < 16; ++t) {
+                const int ks = t >> 3, i = t & 7;
+                if (t + 2 < 16) fp[(t + 2) % 3] = frag(sA, (t + 2) >> 3, wp * 8 + ((t + 2) & 7));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[j], fp, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[ks][j], fp[t % 3], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
             cur ^= 1;
