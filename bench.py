@@ -183,6 +183,22 @@ def main():
                      "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
     }
     if rank == 0:
+        # the InfoNCE kernel group alone (loss + all three gradients) at the 8-GPU global batch B = 4096
+        Bn = 4096
+        x1 = torch.nn.functional.normalize(torch.randn(Bn, E, device=dev), dim=-1).requires_grad_()
+        x2 = torch.nn.functional.normalize(torch.randn(Bn, E, device=dev), dim=-1).requires_grad_()
+        ls = torch.tensor(2.6593, device=dev, requires_grad=True)
+        for _ in range(3):
+            ops.InfoNCEFn.apply(x1, x2, ls, None, 0, Bn, 1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.InfoNCEFn.apply(x1, x2, ls, None, 0, Bn, 1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        nce_ms = e0.elapsed_time(e1) / 10
+        out["infonce_alone"] = {"B": Bn, "E": E, "ms": round(nce_ms, 4), "tflops": round(6.0 * Bn * Bn * E / (nce_ms * 1e-3) / 1e12, 1),
+                                "note": "loss + dx1 + dx2 + dlogit_scale, B x B logits never stored"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, T, Fq)
         print(json.dumps(out), flush=True)

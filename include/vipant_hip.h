@@ -147,6 +147,17 @@ int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, const float* lo
                                int64_t B, int64_t E, int64_t row0, int64_t nrows, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ---- Retrieval evaluation (LossHead.report / retrieval_eval, cvap/module/decoder/loss_head.py:71-168) ----
+ * x1 fp32 [N1, E] queries, x2 fp32 [N2, E] candidates (both L2-normalised by the caller), gold int32 [N1, G]
+ * with entries in [0, N2).  Replaces `(x1 @ x2.t()).argsort(descending=True)` + `torch.where(ind == label)`:
+ *   ranks[i, g] = #{ j : sim[i, j] > sim[i, gold[i, g]] }   (0-based position of the gold column in the sort)
+ *   top1[i]     = argmax_j sim[i, j] (lowest j on ties); may be NULL.
+ * The N1 x N2 similarity matrix is never stored.  E % 64 == 0, 1 <= G <= 64. */
+size_t vipant_retrieval_workspace_bytes(int64_t N1, int64_t N2, int64_t E, int64_t G);
+int32_t vipant_retrieval_ranks(const float* x1, const float* x2, const int32_t* gold, int32_t* ranks, int32_t* top1,
+                               int64_t N1, int64_t N2, int64_t E, int64_t G, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ---- LARS (cvap/module/lars.py:43-72), one fused pass per tensor list ---------------------------------
  * For tensor i (n[i] elements): dp = g + wd*p (adapt[i]); q = eta*|p|/|dp| (adapt[i], both norms > 0);
  * mu = momentum*mu + q*dp; p -= lr[i]*mu.  ptrs are device arrays of device pointers. */

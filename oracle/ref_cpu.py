@@ -248,16 +248,85 @@ def valce_loss_head(x1, x2, x3, scales: Dict[str, Tensor], *, va: bool, lv: bool
     return loss
 
 
-def retrieval_report(x1s: Tensor, x2s: Tensor) -> str:
-    """cvap/module/decoder/loss_head.py:109-134, 243 -- equal-size branch of LossHead.report."""
+def retrieval_metrics(ranks: Tensor, nsample=None, msg: str = "") -> str:
+    """cvap/module/decoder/loss_head.py:68-78."""
+    nsample = nsample or ranks.shape[0]
+    hit = lambda k: torch.where(ranks < k)[0].shape[0] / nsample * 100.0
+    med, avg = ranks.median() + 1, ranks.mean() + 1
+    return f"{msg}: R@1 {hit(1):2.2f} R5 {hit(5):2.2f} R10 {hit(10):2.2f} R50 {hit(50):2.2f} MED {med:2.2f} AVG {avg:2.2f}"
+
+
+def retrieval_eval(x1s: Tensor, x2s: Tensor, k: int = 5) -> str:
+    """cvap/module/decoder/loss_head.py:80-107: best rank among a clip's k captions; rank of a caption's clip."""
     n = x1s.shape[0]
-    labels = torch.arange(n).unsqueeze(-1)
-    r12 = torch.where((x1s @ x2s.t()).argsort(descending=True) == labels)[1]
-    r21 = torch.where((x2s @ x1s.t()).argsort(descending=True) == labels)[1]
-    t = lambda r, k: torch.where(r < k)[0].shape[0] / n * 100.0
-    p12 = f"I->A: t1 = {t(r12, 1):2.2f} t5 = {t(r12, 5):2.2f}"
-    p21 = f"A->I: t1 = {t(r21, 1):2.2f} t5 = {t(r21, 5):2.2f}"
-    return f"{p12} {p21} @ {n}"
+    pos12 = (x1s @ x2s.t()).argsort(descending=True).argsort()          # pos12[i, j] = rank of column j in row i
+    ranks = pos12.reshape(n, n, k)[torch.arange(n), torch.arange(n)].min(-1)[0].float()
+    msg_12 = retrieval_metrics(ranks, msg="A->T")
+    pos21 = (x2s @ x1s.t()).argsort(descending=True).argsort()
+    ranks = pos21[torch.arange(n * k), torch.arange(n).repeat_interleave(k)].float()
+    return f"{msg_12}\n{retrieval_metrics(ranks, msg='T->A')}"
+
+
+def _class_stats(top1, ids, sample_by_classname, classname_by_sample, nsample, msg) -> str:
+    """cvap/module/decoder/loss_head.py:176-232 at k = 1 (nearest neighbour in the gold class or not)."""
+    tp = {}
+    for idx, nb in enumerate(top1):
+        cname = classname_by_sample.get(ids[idx], "")
+        if cname not in sample_by_classname:
+            sample_by_classname[cname] = []                  # the reference's defaultdict grows on lookup
+        tp.setdefault(cname, {}).setdefault(ids[idx], 0)
+        tp[cname][ids[idx]] += int(ids[nb] in sample_by_classname[cname])
+    p = r = p_cls = r_cls = 0.0
+    for cname, per_sample in tp.items():
+        nrel = len(sample_by_classname[cname])
+        pc = sum(v / 1 for v in per_sample.values()); rc = sum(v / nrel for v in per_sample.values())
+        p += pc; r += rc; p_cls += pc / nrel; r_cls += rc / nrel
+    nclass = len(sample_by_classname)
+    return (f"{msg}: P@1 {p / nsample * 100:2.2f} R@1 {r / nsample * 100:2.2f} "
+            f"mAP {p_cls / nclass * 100:2.2f} mAR {r_cls / nclass * 100:2.2f}")
+
+
+def retrieval_report(x1s: Tensor, x2s: Tensor, ids=None, gold_file=None) -> str:
+    """cvap/module/decoder/loss_head.py:109-244 -- LossHead.report: equal-size, 1-vs-5 and shape-mismatch branches,
+    per-class nearest-neighbour statistics when a gold file is given."""
+    import json
+    n1, n2 = x1s.shape[0], x2s.shape[0]
+    ref = stats = ""
+    if n1 == n2:
+        labels = torch.arange(n1).unsqueeze(-1)
+        ind_12 = (x1s @ x2s.t()).argsort(descending=True)
+        ind_21 = (x2s @ x1s.t()).argsort(descending=True)
+        r12 = torch.where(ind_12 == labels)[1]
+        r21 = torch.where(ind_21 == labels)[1]
+        t = lambda r, k: torch.where(r < k)[0].shape[0] / n1 * 100.0
+        p12 = f"I->A: t1 = {t(r12, 1):2.2f} t5 = {t(r12, 5):2.2f}"
+        p21 = f"A->I: t1 = {t(r21, 1):2.2f} t5 = {t(r21, 5):2.2f}"
+        if gold_file is not None:
+            by_class, by_sample = {}, {}
+            with open(gold_file) as fr:
+                for iline, line in enumerate(fr):
+                    if iline + 1 > n1:
+                        break
+                    rec = json.loads(line)
+                    key = " ".join(rec["labels"])
+                    by_class.setdefault(key, []).append(rec["id"]); by_sample[rec["id"]] = key
+            m12 = _class_stats(ind_12[:, 0].tolist(), ids, by_class, by_sample, n1, "I->A")
+            m21 = _class_stats(ind_21[:, 0].tolist(), ids, by_class, by_sample, n1, "A->I")
+            stats = f"\n{m12} {m21}\n"
+    elif n1 * 5 == n2:
+        pos12 = (x1s @ x2s.t()).argsort(descending=True).argsort()
+        r12 = pos12.reshape(n1, n1, 5)[torch.arange(n1), torch.arange(n1)]                  # [n1, 5]
+        t1 = (r12 < 1).sum(-1).sum() / (1 * n1) * 100.0
+        t5 = (r12 < 5).sum(-1).sum() / (5 * n1) * 100.0
+        p12 = f"A->T: t1 = {t1:2.2f} t5 = {t5:2.2f} mR = {r12.min(-1)[0].float().mean() + 1:2.2f}"
+        pos21 = (x2s @ x1s.t()).argsort(descending=True).argsort()
+        r21 = pos21[torch.arange(n2), torch.arange(n1).repeat_interleave(5)]
+        q = lambda k: torch.where(r21 < k)[0].shape[0] / n2 * 100.0
+        p21 = f"T->A: t1 = {q(1):2.2f} t5 = {q(5):2.2f} mR = {r21.float().mean() + 1:2.2f}"
+        ref = f"\nREFERENCE\n{retrieval_eval(x1s, x2s)}"
+    else:
+        p12, p21 = f"{x1s.shape}x{x2s.shape}", "-"
+    return f"{stats}{p12} {p21} @ {n1}{ref}"
 
 
 # --------------------------------------------------------------------------- worker glue

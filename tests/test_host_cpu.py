@@ -145,15 +145,6 @@ def test_lr_schedule_matches_reference(golden):
     assert M.exclude_bias_or_norm(torch.zeros(3)) and not M.exclude_bias_or_norm(torch.zeros(3, 3))
 
 
-def test_retrieval_report_matches_reference(golden):
-    g = golden("report")
-    lh = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
-    x1 = gen.det_randn("report/x1", (40, 512)); x2 = x1 + 0.9 * gen.det_randn("report/x2", (40, 512))
-    x1 = x1 / x1.norm(dim=-1, keepdim=True); x2 = x2 / x2.norm(dim=-1, keepdim=True)
-    lh.x1s, lh.x2s, lh.ids = [x1[:25], x1[25:]], [x2[:25], x2[25:]], []
-    assert lh.report() == str(g["report"])
-
-
 def test_worker_build_and_tunable_sets():
     """cvap/model/cvalp.py:217-267 (VA) and :130-215 (AT): which parameters train."""
     cfg = compose(VA + ["model.image.encoder.layers=1", "running.audio.max_len=256", "running.audio.num_mel_bins=64"])

@@ -336,3 +336,65 @@ def test_layernorm_fused_residual_add(ops):
     assert_close(xs, ref_sum, 1e-6, 1e-6, "x + branch")
     assert_close(h, torch.nn.functional.layer_norm(ref_sum, (D,), gm.double(), bt.double(), 1e-5), 1e-2, 1e-2, "ln(x + branch)")
     assert_close(ops.residual_add(x, y), ref_sum, 1e-6, 1e-6, "residual_add")
+
+
+# ------------------------------------------------------------------------------------------ retrieval evaluation
+@pytest.mark.parametrize("N1,N2,G", [(40, 40, 1), (36, 180, 5), (700, 3500, 5), (1000, 513, 3), (257, 256, 1)])
+def test_retrieval_ranks_match_argsort(ops, N1, N2, G):
+    """ranks == position of the gold column in the reference's descending argsort (loss_head.py:113-118)."""
+    g = torch.Generator().manual_seed(7)
+    x1 = torch.nn.functional.normalize(torch.randn(N1, 512, generator=g), dim=-1)
+    x2 = torch.nn.functional.normalize(torch.randn(N2, 512, generator=g), dim=-1)
+    x2[: min(N1, N2)] += 0.2 * x1[: min(N1, N2)]                      # some structure
+    x2 = torch.nn.functional.normalize(x2, dim=-1)
+    gold = torch.randint(0, N2, (N1, G), generator=g)
+    sim = x1.double() @ x2.double().t()
+    pos = sim.argsort(descending=True).argsort()
+    want = torch.gather(pos, 1, gold)
+    ranks, top1 = ops.retrieval_ranks(x1.to(DEV), x2.to(DEV), gold.to(DEV), want_top1=True)
+    assert ranks.shape == (N1, G) and ranks.dtype == torch.int32
+    got = ranks.cpu().long()
+    # similarities are fp32-grade (hi/lo bf16 split): the rank may differ from the exact one only by candidates
+    # whose similarity is within 2e-6 of the gold's
+    gs = torch.gather(sim, 1, gold)                                    # [N1, G]
+    lo = (sim.unsqueeze(1) > (gs + 2e-6).unsqueeze(2)).sum(-1)
+    hi = (sim.unsqueeze(1) > (gs - 2e-6).unsqueeze(2)).sum(-1)
+    assert bool(((got >= lo) & (got <= hi)).all())
+    assert (got != want).float().mean() < 2e-2      # an fp32 GEMM disagrees with the exact order about as often
+    best = torch.gather(sim, 1, top1.cpu().long()[:, None])[:, 0]
+    assert bool((sim.max(1)[0] - best < 2e-6).all())
+    assert (top1.cpu().long() != sim.argmax(1)).float().mean() < 2e-2
+
+
+def test_retrieval_report_goldens(golden):
+    """LossHead.report strings against the reference's own output (tests/golden/make_golden.py, section vii)."""
+    import os
+    from vipant_amd import module as M
+    from types import SimpleNamespace as NS
+    import gen
+    lh = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None)).to(DEV)
+    lh.eval()
+    x1 = gen.det_randn("report/x1", (40, 512)); x2 = x1 + 0.9 * gen.det_randn("report/x2", (40, 512))
+    x1 = x1 / x1.norm(dim=-1, keepdim=True); x2 = x2 / x2.norm(dim=-1, keepdim=True)
+    x1, x2 = x1.to(DEV), x2.to(DEV)
+    lh(x1[:25], x2[:25], normalized=True); lh(x1[25:], x2[25:], normalized=True)
+    assert lh.report() == str(golden("report")["report"])
+    g = golden("report_protocols")
+    h2 = x1.cpu() + 0.45 * gen.det_randn("report/hard", (40, 512)); h2 = (h2 / h2.norm(dim=-1, keepdim=True)).to(DEV)
+    lh(x1, h2, normalized=True)
+    assert lh.report() == str(g["report_hard"])
+    n = 36
+    a = gen.det_randn("report5/a", (n, 512)); t = a.repeat_interleave(5, 0) + 9.0 * gen.det_randn("report5/t", (5 * n, 512))
+    a = (a / a.norm(dim=-1, keepdim=True)).to(DEV); t = (t / t.norm(dim=-1, keepdim=True)).to(DEV)
+    lh(a[:20], t[:100], normalized=True); lh(a[20:], t[100:], normalized=True)
+    assert lh.report() == str(g["report_1v5"])
+    names = [f"clip{i:03d}" for i in range(40)]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "report_gold.jsonl")
+    lh(x1[:25], h2[:25], normalized=True, names=names[:25]); lh(x1[25:], h2[25:], normalized=True, names=names[25:])
+    assert lh.report(gold_file=gold) == str(g["report_gold"])
+    lh(x1[:7], h2[:9], normalized=True)
+    assert lh.report() == str(g["report_mismatch"])
+    # un-normalised inputs are normalised on the way in (loss_head.py:38-41)
+    lh(3.0 * x1, 0.5 * h2)
+    assert lh.report() == str(g["report_hard"])
+

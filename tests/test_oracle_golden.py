@@ -174,3 +174,25 @@ def test_report(golden):
     x1 = gen.det_randn("report/x1", (40, 512)); x2 = x1 + 0.9 * gen.det_randn("report/x2", (40, 512))
     x1 = x1 / x1.norm(dim=-1, keepdim=True); x2 = x2 / x2.norm(dim=-1, keepdim=True)
     assert R.retrieval_report(x1, x2) == str(g["report"])
+
+
+def _report_inputs():
+    x1 = gen.det_randn("report/x1", (40, 512)); x1 = x1 / x1.norm(dim=-1, keepdim=True)
+    h2 = x1 + 0.45 * gen.det_randn("report/hard", (40, 512)); h2 = h2 / h2.norm(dim=-1, keepdim=True)
+    n = 36
+    a = gen.det_randn("report5/a", (n, 512)); t = a.repeat_interleave(5, 0) + 9.0 * gen.det_randn("report5/t", (5 * n, 512))
+    return x1, h2, a / a.norm(dim=-1, keepdim=True), t / t.norm(dim=-1, keepdim=True)
+
+
+def test_report_protocols(golden):
+    """LossHead.report: hard equal-size case, 1 clip vs 5 captions (+ retrieval_eval block), gold-file class statistics."""
+    import os
+    g = golden("report_protocols")
+    x1, h2, a, t = _report_inputs()
+    assert R.retrieval_report(x1, h2) == str(g["report_hard"])
+    assert R.retrieval_report(a, t) == str(g["report_1v5"])
+    names = [f"clip{i:03d}" for i in range(40)]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "report_gold.jsonl")
+    assert R.retrieval_report(x1, h2, ids=names, gold_file=gold) == str(g["report_gold"])
+    assert R.retrieval_report(x1[:7], h2[:9]) == str(g["report_mismatch"])
+

@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvipant_hip.so")
+LIB_PATH = os.environ.get("VIPANT_HIP_LIB") or os.path.join(_HERE, "lib", "libvipant_hip.so")   # override: A/B timing of builds
 
 EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32 = range(6)
 
@@ -50,6 +50,8 @@ PROTOTYPES = {
     "vipant_scatter_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_infonce_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_infonce_fwd_bwd": (_i32, [_p, _p, _p, _f32, _p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "vipant_retrieval_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vipant_retrieval_ranks": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_lars_workspace_bytes": (_sz, [_i64]),
     "vipant_lars_step": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _p, _sz, _p]),
 }

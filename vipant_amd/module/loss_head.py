@@ -3,9 +3,12 @@
 Training path: `CELossHead.forward` = symmetric InfoNCE through the fused HIP kernels (ops.InfoNCEFn); in a
 replica group the features are first all-gathered so every rank scores the GLOBAL batch -- the semantics of
 the reference's dp mode, where the loss head sees the gathered batch (cvap/model/cvalp.py:41-61).
-Eval path: `infer` caches normalised features, `report` computes retrieval top-1 / top-5 (host side).
+Eval path: `infer` caches normalised features on the device, `report` ranks them with the fused retrieval kernels.
 """
 from __future__ import annotations
+
+import json
+from collections import defaultdict
 
 import numpy as np
 import torch
@@ -23,7 +26,11 @@ def build_loss_head(cfg, **kwargs):
 
 
 class LossHead(nn.Module):
-    """cvap/module/decoder/loss_head.py:25-244 (feature cache + equal-size retrieval report)."""
+    """cvap/module/decoder/loss_head.py:25-244: feature cache (`infer`) and the retrieval report.
+
+    The reference sorts every row of `x1s @ x2s.t()` and looks up the gold column; here the ranks come from
+    `ops.retrieval_ranks` (fused similarity tiles + counting on the GPU, nothing N x N is stored).  What is left on
+    the host is the formatting of a few counters, done in the reference's own dtypes so the strings agree."""
 
     def __init__(self):
         super().__init__()
@@ -37,43 +44,117 @@ class LossHead(nn.Module):
         if not hasattr(self, "x1s") or not hasattr(self, "x2s") or not hasattr(self, "ids"):
             self.x1s, self.x2s, self.ids = [], [], []
         if not kwargs.get("normalized", False):
-            x1, x2 = ops.l2_normalize(x1), ops.l2_normalize(x2)
-        self.x1s.append(x1.detach().float().cpu())
-        self.x2s.append(x2.detach().float().cpu())
+            x1, x2 = ops.l2_normalize(x1.detach().float()), ops.l2_normalize(x2.detach().float())
+        self.x1s.append(x1.detach().float())
+        self.x2s.append(x2.detach().float())
         names = kwargs.get("names", None)
         if names is not None:
             self.ids.extend(names)
         return None
 
     @staticmethod
-    def _ranks(sim: np.ndarray, gold: np.ndarray) -> np.ndarray:
-        """Position of the gold column in a descending sort of each row (loss_head.py:116-118) without sorting."""
-        g = sim[np.arange(sim.shape[0]), gold][:, None]
-        return (sim > g).sum(1)
+    def _gold_cluster(gold_file, nsample, verbose=False):
+        """loss_head.py:48-66: class name ("labels" joined by blanks) <-> sample ids, first `nsample` records."""
+        sample_by_classname, classname_by_sample = defaultdict(list), defaultdict(str)
+        with open(gold_file, "r") as fr:
+            for iline, line in enumerate(fr):
+                if iline + 1 > nsample:
+                    break
+                record = json.loads(line)
+                key = " ".join(record["labels"])
+                sample_by_classname[key].append(record["id"])
+                classname_by_sample[record["id"]] = key
+        return sample_by_classname, classname_by_sample
+
+    @staticmethod
+    def retrieval_metrics(ranks, nsample=None, msg=""):
+        """loss_head.py:68-78; `ranks` is a float32 vector as in the reference (median = lower median)."""
+        ranks = torch.as_tensor(ranks).float().cpu()
+        nsample = nsample or ranks.shape[0]
+        hit = lambda k: int((ranks < k).sum()) / nsample * 100.
+        med, avg = ranks.median() + 1, ranks.mean() + 1
+        return (f"{msg}: R@1 {hit(1):2.2f} R5 {hit(5):2.2f} R10 {hit(10):2.2f} R50 {hit(50):2.2f} "
+                f"MED {med:2.2f} AVG {avg:2.2f}")
+
+    @staticmethod
+    def _one_v_k_ranks(x1s, x2s, k=5):
+        """ranks of the k captions of every clip (x1 -> x2, [n1, k]) and of every caption's clip (x2 -> x1, [n1 * k])."""
+        n1 = x1s.shape[0]
+        gold12 = torch.arange(n1 * k, dtype=torch.int32).reshape(n1, k)
+        gold21 = torch.arange(n1, dtype=torch.int32).repeat_interleave(k)
+        return ops.retrieval_ranks(x1s, x2s, gold12).cpu(), ops.retrieval_ranks(x2s, x1s, gold21).cpu()
+
+    @staticmethod
+    def retrieval_eval(x1s, x2s, k=5, _ranks=None):
+        """loss_head.py:80-107: best-caption rank per clip and clip rank per caption."""
+        r12, r21 = _ranks if _ranks is not None else LossHead._one_v_k_ranks(x1s, x2s, k)
+        msg_12 = LossHead.retrieval_metrics(r12.min(-1)[0], msg="A->T")
+        msg_21 = LossHead.retrieval_metrics(r21, msg="T->A")
+        return f"{msg_12}\n{msg_21}"
+
+    def _class_stats(self, top1, sample_by_classname, classname_by_sample, nsample, msg, k=1):
+        """loss_head.py:176-232 (topk_overlap + pnr at k = 1): precision / recall of the nearest neighbour by class."""
+        stats = defaultdict(dict)
+        for idx, neighbor in enumerate(top1):
+            sample = self.ids[idx]
+            classname = classname_by_sample[sample]
+            true_neighbors = sample_by_classname[classname]
+            sample_stat = stats.get(classname, {})
+            this_stat = sample_stat.get(sample, [0] * 2)
+            if self.ids[neighbor] in true_neighbors:
+                this_stat[0] += 1
+            sample_stat[sample] = this_stat
+            stats[classname] = sample_stat
+        p = r = p_cls = r_cls = 0.
+        nclass = len(sample_by_classname)
+        for classname, class_stats in stats.items():
+            nrelevant = len(sample_by_classname[classname])
+            pc = rc = 0
+            for sample, (tp, _) in class_stats.items():
+                p += tp / k; r += tp / nrelevant
+                pc += tp / k; rc += tp / nrelevant
+            p_cls += pc / nrelevant
+            r_cls += rc / nrelevant
+        p, r = (p / nsample) * 100, (r / nsample) * 100
+        p_cls, r_cls = (p_cls / nclass) * 100, (r_cls / nclass) * 100
+        return f"{msg}: P@{k} {p:2.2f} R@{k} {r:2.2f} mAP {p_cls:2.2f} mAR {r_cls:2.2f}"
 
     def report(self, gold_file=None):
-        x1s, x2s = torch.cat(self.x1s).numpy(), torch.cat(self.x2s).numpy()
+        x1s, x2s = torch.cat(self.x1s), torch.cat(self.x2s)
         n1, n2 = x1s.shape[0], x2s.shape[0]
+        ref_metric = ""
+        top12 = top21 = None
         if n1 == n2:
-            sim = x1s @ x2s.T
-            r12 = self._ranks(sim, np.arange(n1))
-            r21 = self._ranks(sim.T, np.arange(n1))
-            pct = lambda r, k: float((r < k).sum()) / n1 * 100.0
+            gold = torch.arange(n1, dtype=torch.int32)
+            r12, top12 = ops.retrieval_ranks(x1s, x2s, gold, want_top1=True)
+            r21, top21 = ops.retrieval_ranks(x2s, x1s, gold, want_top1=True)
+            pct = lambda r, k: int((r < k).sum()) / n1 * 100.
             p_12 = f"I->A: t1 = {pct(r12, 1):2.2f} t5 = {pct(r12, 5):2.2f}"
             p_21 = f"A->I: t1 = {pct(r21, 1):2.2f} t5 = {pct(r21, 5):2.2f}"
-        elif n1 * 5 == n2:   # 1 audio vs 5 captions (loss_head.py:135-168)
-            sim = x1s @ x2s.T
-            r12 = np.stack([self._ranks(sim, np.arange(n1) * 5 + j) for j in range(5)], 1)
-            t1 = float((r12 < 1).sum()) / n1 * 100.0
-            t5 = float((r12 < 5).sum()) / (5 * n1) * 100.0
-            p_12 = f"A->T: t1 = {t1:2.2f} t5 = {t5:2.2f} mR = {r12.min(1).astype(np.float32).mean() + 1:2.2f}"
-            r21 = self._ranks(sim.T, np.repeat(np.arange(n1), 5))
-            p_21 = (f"T->A: t1 = {float((r21 < 1).sum()) / n2 * 100.0:2.2f} t5 = {float((r21 < 5).sum()) / n2 * 100.0:2.2f} "
-                    f"mR = {r21.astype(np.float32).mean() + 1:2.2f}")
+        elif n1 * 5 == n2:   # 1 clip vs 5 captions (loss_head.py:135-168)
+            r12, r21 = self._one_v_k_ranks(x1s, x2s, 5)
+            t1 = (r12 < 1).sum(-1).sum() / (1 * n1) * 100.     # float32 tensors, as in the reference
+            t5 = (r12 < 5).sum(-1).sum() / (5 * n1) * 100.
+            mean = r12.min(-1)[0].float().mean() + 1
+            p_12 = f"A->T: t1 = {t1:2.2f} t5 = {t5:2.2f} mR = {mean:2.2f}"
+            t1 = int((r21 < 1).sum()) / n2 * 100.
+            t5 = int((r21 < 5).sum()) / n2 * 100.
+            mean = r21.float().mean() + 1
+            p_21 = f"T->A: t1 = {t1:2.2f} t5 = {t5:2.2f} mR = {mean:2.2f}"
+            ref_metric = self.retrieval_eval(x1s, x2s, _ranks=(r12, r21))
+            gold_file = None
         else:
-            p_12, p_21 = f"{tuple(x1s.shape)}x{tuple(x2s.shape)}", "-"
+            p_12, p_21 = f"{x1s.shape}x{x2s.shape}", "-"
+            gold_file = None
+        msg_12 = msg_21 = ""
+        if gold_file is not None:
+            by_class, by_sample = self._gold_cluster(gold_file, n1)
+            msg_12 = self._class_stats(top12.tolist(), by_class, by_sample, n1, "I->A")
+            msg_21 = self._class_stats(top21.tolist(), by_class, by_sample, n1, "A->I")
         del self.x1s, self.x2s, self.ids
-        return f"{p_12} {p_21} @ {n1}"
+        msg = "" if msg_12 == msg_21 == "" else f"\n{msg_12} {msg_21}\n"
+        ref = "" if ref_metric == "" else f"\nREFERENCE\n{ref_metric}"
+        return f"{msg}{p_12} {p_21} @ {n1}{ref}"
 
 
 @LOSS_HEADS_REGISTRY.register()

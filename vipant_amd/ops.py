@@ -481,6 +481,27 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def retrieval_ranks(x1: torch.Tensor, x2: torch.Tensor, gold: torch.Tensor, want_top1: bool = False):
+    """Rank of the gold candidates of every query without sorting (cvap/module/decoder/loss_head.py:113-118, 141-160):
+    x1 [N1, E], x2 [N2, E] fp32 L2-normalised, gold int [N1] or [N1, G] -> ranks int32 of gold's shape
+    (= torch.where((x1 @ x2.t()).argsort(descending=True) == gold)[1]) and, optionally, top1 int32 [N1]."""
+    _need(x1, F32, "retrieval.x1"); _need(x2, F32, "retrieval.x2")
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    if gold.device != x1.device or gold.dtype != torch.int32:
+        gold = gold.to(device=x1.device, dtype=torch.int32)
+    shape = tuple(gold.shape)
+    gold2 = gold.reshape(x1.shape[0], -1).contiguous()
+    N1, E = x1.shape
+    N2, G = x2.shape[0], gold2.shape[1]
+    ranks = torch.empty((N1, G), dtype=torch.int32, device=x1.device)
+    top1 = torch.empty((N1,), dtype=torch.int32, device=x1.device) if want_top1 else None
+    ws = scratch("retrieval", query("vipant_retrieval_workspace_bytes", N1, N2, E, G), x1.device)
+    call("vipant_retrieval_ranks", x1.data_ptr(), x2.data_ptr(), gold2.data_ptr(), ranks.data_ptr(), _ptr(top1), N1, N2, E, G,
+         ws.data_ptr(), ws.numel(), _stream())
+    ranks = ranks.reshape(shape)
+    return (ranks, top1) if want_top1 else ranks
+
+
 class L2NormFn(torch.autograd.Function):
     """x / ||x|| (cvap/module/decoder/loss_head.py:272-273) with its backward, for un-normalised head outputs."""
 
