@@ -158,6 +158,22 @@ int32_t vipant_retrieval_ranks(const float* x1, const float* x2, const int32_t* 
                                int64_t N1, int64_t N2, int64_t E, int64_t G, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ---- Log-mel front-end (cvap/data/audio/transform.py:12-35 -> torchaudio.compliance.kaldi.fbank with the parameters
+ * of cvap/data/image_audio.py:119-126; padding / normalisation / SpecAugment masks of image_audio.py:183-207) ----
+ * wave fp32 [b, wave_stride] (clip i valid for nsamples[i] samples), out fp32 [b, T, F] (= [b, 1, T, F]).
+ * Frames: snip_edges, window_size / window_shift samples, zero-padded to nfft (512 / 1024 / 2048); per-frame DC removal,
+ * pre-emphasis, `window` [window_size] (symmetric Hann for the reference), power spectrum, `banks` fp32 [F, nfft/2+1]
+ * triangular mel weights whose non-zero support of row m is [bank_start[m], bank_start[m] + bank_len[m]), log with the
+ * fp32-epsilon floor.  Frames past a clip's last whole window are 0 before normalisation.  zero_mean != 0 subtracts the
+ * clip mean first (zero_mean_wf).  norm_std != 0: (x - norm_mean) / norm_std.  masks int32 [b, 4] = f0, f1, t0, t1
+ * (SpecAugment: bins [f0, f1) and frames [t0, t1) set to 0), or NULL. */
+size_t vipant_fbank_workspace_bytes(int64_t b);
+int32_t vipant_fbank(const float* wave, int64_t wave_stride, const int64_t* nsamples, float* out, const float* window,
+                     const float* banks, const int32_t* bank_start, const int32_t* bank_len, const int32_t* masks,
+                     int64_t b, int64_t T, int64_t F, int32_t window_size, int32_t window_shift, int32_t nfft,
+                     float preemphasis, int32_t zero_mean, float norm_mean, float norm_std, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* ---- LARS (cvap/module/lars.py:43-72), one fused pass per tensor list ---------------------------------
  * For tensor i (n[i] elements): dp = g + wd*p (adapt[i]); q = eta*|p|/|dp| (adapt[i], both norms > 0);
  * mu = momentum*mu + q*dp; p -= lr[i]*mu.  ptrs are device arrays of device pointers. */

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "vipant_infonce_fwd_bwd": (_i32, [_p, _p, _p, _f32, _p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_retrieval_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "vipant_retrieval_ranks": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
+    "vipant_fbank_workspace_bytes": (_sz, [_i64]),
+    "vipant_fbank": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _f32, _p, _sz, _p]),
     "vipant_lars_workspace_bytes": (_sz, [_i64]),
     "vipant_lars_step": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _p, _sz, _p]),
 }

@@ -45,6 +45,8 @@ class _AllGatherRows(torch.autograd.Function):
             host = torch.empty(out.shape, dtype=x.dtype)      # (single-GPU replica tests only; RCCL takes the direct path)
             dist.all_gather(list(host.chunk(w, dim=0)), x.cpu())
             out.copy_(host)
+        elif dist.get_backend() == "nccl":                    # RCCL: one flat collective, no per-rank output list
+            dist.all_gather_into_tensor(out, x)
         else:
             dist.all_gather(list(out.chunk(w, dim=0)), x)
         ctx.b = x.shape[0]
