@@ -181,19 +181,22 @@ def cast_bf16_flat(x: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-_frozen_cache: Dict[Tuple[int, int, bool], Tuple[torch.Tensor, Optional[torch.Tensor]]] = {}
+_frozen_cache: Dict[tuple, tuple] = {}
 
 
 def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
-    """bf16 copy of a frozen weight, cached until the tensor is modified (frozen towers, eval)."""
-    key = (w.data_ptr(), w._version, transpose_only)
+    """bf16 copy of a frozen weight, cached until the tensor is modified (frozen towers, eval).
+
+    Keyed by address + version + shape; every entry also holds the source's storage, so the address cannot be handed
+    to another tensor while the entry is alive (a freed tower's weights would otherwise alias a later model's)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), transpose_only)
     hit = _frozen_cache.get(key)
     if hit is None:
-        if len(_frozen_cache) > 4096:
-            _frozen_cache.clear()
-        hit = cast_bf16(w.detach(), transpose=transpose_only)
+        while len(_frozen_cache) >= 1024:
+            _frozen_cache.pop(next(iter(_frozen_cache)))
+        hit = (cast_bf16(w.detach(), transpose=transpose_only), w.untyped_storage())
         _frozen_cache[key] = hit
-    return hit[1] if transpose_only else hit[0]
+    return hit[0][1] if transpose_only else hit[0][0]
 
 
 # ---------------------------------------------------------------------------------- patch embedding
