@@ -5,7 +5,7 @@
 //   pass 1  256x256 logit tiles on MFMA (the shared NT main loop); the epilogue reduces each tile to per-row
 //           and per-column (max, sum exp, sum exp*z) triples with wave shuffles and stores only those
 //           (B * #tiles floats instead of B^2) plus the diagonal;
-//   final   one small kernel merges the triples into row / column log-sum-exp, the loss and d logit_scale
+//   final   two small kernels merge the triples into row / column log-sum-exp, the loss and d logit_scale
 //           ( = sum dZ * Z, expressible from the triples );
 //   pass 2  recomputes the tiles that touch this rank's row strip / column strip, forms
 //           s * dZ = s * (softmax_row + softmax_col - 2 I) / B in registers and stores it as bf16;
@@ -21,7 +21,7 @@ using namespace ntcore;
 
 struct NceWs {       // carved out of the caller's workspace; all offsets 256-B aligned
     bf16_t *x1cat, *x2cat, *x2t, *dz;
-    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal;   // scal[0] = s, scal[1] = clamped
+    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part;   // scal[0] = s, scal[1] = clamped
     void* tn_ws;
     size_t tn_bytes, total;
     int Bp, rparts, cparts;
@@ -46,6 +46,7 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     w.cwz = (float*)take((size_t)w.cparts * B * 4);
     w.diag = (float*)take((size_t)B * 4); w.rlse = (float*)take((size_t)B * 4); w.clse = (float*)take((size_t)B * 4);
     w.scal = (float*)take(256);
+    w.part = (float*)take((size_t)ceil_div(B, 256) * 2 * 4);
     w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
     w.tn_ws = take(w.tn_bytes);
     w.total = off;
@@ -198,12 +199,15 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
     }
 }
 
-// Merge the per-tile triples; single workgroup (B <= 64k is tiny work).  loss = mean(rlse - d) + mean(clse - d);
+// Merge the per-tile triples: one thread per row/column index, 256 per workgroup; every workgroup leaves its two
+// partial sums in the workspace and a one-workgroup kernel adds them in a fixed order (reproducible).
+// loss = mean(rlse - d) + mean(clse - d);
 // dlogit_scale = gscale/B * (sum_i E_row[i] + sum_j E_col[j] - 2 sum_i d_i), zero when the scale is clamped.
-__global__ __launch_bounds__(1024) void nce_final_kernel(NceWs w, int B, float gscale, float* loss, float* dls) {
-    __shared__ float red[2][1024];
+__global__ __launch_bounds__(256) void nce_merge_kernel(NceWs w, int B) {
+    __shared__ float red[2][256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
     float lsum = 0.f, esum = 0.f;
-    for (int i = threadIdx.x; i < B; i += 1024) {
+    if (i < B) {
         float acc2[2][2];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
@@ -227,12 +231,25 @@ __global__ __launch_bounds__(1024) void nce_final_kernel(NceWs w, int B, float g
             acc2[side][1] = sw / se;
         }
         const float d = w.diag[i];
-        lsum += (acc2[0][0] - d) + (acc2[1][0] - d);
-        esum += acc2[0][1] + acc2[1][1] - 2.f * d;
+        lsum = (acc2[0][0] - d) + (acc2[1][0] - d);
+        esum = acc2[0][1] + acc2[1][1] - 2.f * d;
     }
     red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = esum;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { w.part[2 * blockIdx.x] = red[0][0]; w.part[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+__global__ __launch_bounds__(256) void nce_final_kernel(NceWs w, int B, int nparts, float gscale, float* loss, float* dls) {
+    __shared__ float red[2][256];
+    float lsum = 0.f, esum = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) { lsum += w.part[2 * i]; esum += w.part[2 * i + 1]; }
+    red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = esum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
         __syncthreads();
     }
@@ -272,7 +289,10 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_tile_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, 0, (int)B, 1.0f);
     VIPANT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(1024), 0, s, w, (int)B, grad_scale, loss, dlogit_scale);
+    const int nparts = (int)ceil_div(B, 256);
+    hipLaunchKernelGGL(nce_merge_kernel, dim3((unsigned)nparts), dim3(256), 0, s, w, (int)B);
+    VIPANT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(256), 0, s, w, (int)B, nparts, grad_scale, loss, dlogit_scale);
     VIPANT_LAUNCH_CHECK();
     if ((dx1 == nullptr && dx2 == nullptr) || nrows == 0) return VIPANT_OK;
     hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)row0, (int)nrows, grad_scale);
