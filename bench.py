@@ -105,7 +105,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)      # launched by torch.distributed.run
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from vipant_amd import _ffi, ops, parallel
@@ -143,18 +144,18 @@ def main():
     S = mon.model.audio_head.misc.positional_embedding.shape[0]
     Mrows = b * S
     ops.KERNEL_PROBE["gemm_nt"] = {"events": [], "match": lambda epi, M, N, K: epi == ops.EPI_QUICKGELU and M == Mrows}
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = one_step(args.warmup + i)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     events = ops.KERNEL_PROBE.pop("gemm_nt")["events"]
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -202,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, T, Fq)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,10 +32,15 @@ def _batch(B):
     return torch.randn(B, 512, generator=g), torch.randn(B, 1, 256, 64, generator=g)
 
 
-def _run(rank, world, port, out):
-    if world > 1:
+def _run(rank, world, port, out, backend="gloo"):
+    if world > 1 or backend == "nccl":
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":                       # single-rank RCCL group with the exchange steps forced on
+            os.environ["VIPANT_FORCE_COLLECTIVES"] = "1"
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vipant_amd.config import compose
         from vipant_amd.module import adjust_learning_rate
@@ -58,7 +63,7 @@ def _run(rank, world, port, out):
             sd = {k: v.detach().cpu() for k, v in mon.model.named_parameters() if v.requires_grad}
             torch.save({"loss": float(loss.detach()), "params": sd}, out)
     finally:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
 
 
@@ -74,3 +79,18 @@ def test_two_replicas_match_single_process(tmp_path):
         pa, pb = a["params"][k], b["params"][k]
         err = float((pa - pb).abs().max())
         assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_call_path_single_rank_is_identity(tmp_path):
+    """The RCCL code path itself (flat feature all-gather, per-block bucket all-reduce on the side stream, copy-back into
+    .grad, small-parameter bucket) on the real library: a one-rank `nccl` group with the collectives forced on must give
+    exactly the step of a process without a group."""
+    one, rc = str(tmp_path / "one.pt"), str(tmp_path / "rccl.pt")
+    mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, _free_port(), rc, "nccl"), nprocs=1, join=True)
+    a, b = torch.load(one), torch.load(rc)
+    assert a["loss"] == b["loss"], (a["loss"], b["loss"])
+    for k in a["params"]:
+        assert torch.equal(a["params"][k], b["params"][k]), k
+

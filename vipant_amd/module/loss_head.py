@@ -188,8 +188,7 @@ class CELossHead(LossHead):
         scale_max = 0.0 if self.scale_max == float("inf") else float(self.scale_max)
         ls = self.logit_scale if isinstance(self.logit_scale, nn.Parameter) else self.logit_scale.to(x1.device)
         b = x1.shape[0]
-        world = parallel.world_size()
-        if world > 1 and self.negatives == "global":
+        if parallel.active() and self.negatives == "global":
             x1g, x2g = parallel.all_gather_features(x1, x2)
             return ops.InfoNCEFn.apply(x1g, x2g, ls, scale_max, parallel.rank() * b, b, 1.0)
         return ops.InfoNCEFn.apply(x1, x2, ls, scale_max, 0, b, 1.0)

@@ -80,7 +80,7 @@ class Monitor(object):
         tunable_params = model.build(negatives=negatives)
         self.model = model
         self.grad_sync = None
-        if parallel.world_size() > 1:
+        if parallel.active():
             self.grad_sync = parallel.GradSync()
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):

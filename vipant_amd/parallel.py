@@ -15,6 +15,7 @@ Device-agnostic on purpose: the same code runs under gloo on CPU tensors in test
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -31,6 +32,13 @@ def world_size() -> int:
 
 def rank() -> int:
     return dist.get_rank() if is_dist() else 0
+
+
+def active() -> bool:
+    """Are the exchange steps on?  True in any group of more than one replica.  VIPANT_FORCE_COLLECTIVES=1 turns them on in
+    a single-rank group as well, so the RCCL call path (stream hand-off, flat gather, bucket all-reduce) can be exercised on
+    a one-GPU box, where it must be the identity (tests/test_replicas_gpu.py)."""
+    return is_dist() and (dist.get_world_size() > 1 or os.environ.get("VIPANT_FORCE_COLLECTIVES") == "1")
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -85,7 +93,7 @@ class GradSync:
         `flat` that are the gradients of `params`: autograd usually CLONES a gradient it is handed while other
         references to it exist, so after the reduction `wait()` copies the reduced slices over whatever tensor ended
         up in `param.grad`."""
-        if world_size() == 1:
+        if not active():
             return
         if views is not None:
             self.pairs.extend(zip(params, views))
@@ -102,7 +110,7 @@ class GradSync:
     def reduce_params(self, params: Iterable[torch.nn.Parameter]):
         """Bucket the (small) gradients that did not come through a layer bucket: patch embedding, read-out."""
         grads = [p.grad for p in params if p.grad is not None]
-        if world_size() == 1 or not grads:
+        if not active() or not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
         self.reduce_async(flat)
