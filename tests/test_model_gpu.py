@@ -88,6 +88,31 @@ def test_block_golden(M, golden, tag, D, S, b, causal):
     assert rel_err(sl["resblocks.0.mlp.c_fc.weight"].grad[::131, ::17], g["g_c_fc_w_rows"]) < 4e-2
 
 
+@pytest.mark.parametrize("D,S,b,layers", [(1024, 50, 2, 2), (768, 306, 1, 1), (256, 17, 3, 1)])
+def test_backbone_other_widths_match_oracle(M, D, S, b, layers):
+    """Widths beyond the two reference towers (ViT-L's 1024 = BASELINE configs[4], heads = width // 64, val.py:474) and the
+    shipped-default token count (T=1000 -> S=306): HIP stack against the CPU restatement."""
+    from oracle import ref_cpu as R
+    bb = M.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=D, ctx_len=None)
+    w = gen.det_weights(f"wide/{D}", gen.backbone_shapes(D, layers))
+    sd = {k[len("encoder."):]: v for k, v in w.items()}
+    bb.load_state_dict(sd, strict=True)
+    bb = bb.to(DEV)
+    x = gen.det_randn(f"wide/{D}/x", (b, S, D))
+    gy = gen.det_randn(f"wide/{D}/gy", (b, S, D))
+    xr = x.clone().requires_grad_()
+    sdr = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    yr = R.transformer_backbone(xr, sdr, "", layers, D, None, True)          # the restatement is batch-first
+    yr.backward(gy)
+    xg = x.to(DEV).requires_grad_()
+    y = bb(xg)
+    y.backward(gy.to(DEV))
+    assert rel_err(y, yr.detach()) < 2e-2, rel_err(y, yr.detach())
+    assert rel_err(xg.grad, xr.grad) < 4e-2, rel_err(xg.grad, xr.grad)
+    for k, p in bb.named_parameters():
+        assert rel_err(p.grad, sdr[k].grad) < 5e-2, (k, rel_err(p.grad, sdr[k].grad))
+
+
 @pytest.mark.parametrize("tag,T,Fq,b", [("256x64", 256, 64, 3), ("1024x128", 1024, 128, 2)])
 def test_pre_post_golden(M, golden, tag, T, Fq, b):
     g = golden(f"prepost_{tag}")
