@@ -140,26 +140,52 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
 
         f32x4 s[NT];
         float m = -INFINITY;
+        // Fragment pipeline (as in the contractions): the K row fragments of key-tile pair u + 2 are requested before the
+        // MFMAs of pair u, through a 3-deep register ring, so an LDS round trip is never exposed in front of an MFMA group.
+        bf16x8 kr[3][4];
+        auto k_pair = [&](int u, bf16x8 (&f)[4]) {
+            f[0] = img_row_frag(kimg, il, 2 * u, 0); f[1] = img_row_frag(kimg, il, 2 * u, 1);
+            f[2] = img_row_frag(kimg, il, 2 * u + 1, 0); f[3] = img_row_frag(kimg, il, 2 * u + 1, 1);
+        };
+        k_pair(0, kr[0]);
+        if (NT > 2) k_pair(1, kr[1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, acc, 0, 0, 0);
+        for (int u = 0; u < NT / 2; ++u) {
+            if (u + 2 < NT / 2) k_pair(u + 2, kr[(u + 2) % 3]);
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u % 3][0], qf0, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u % 3][2], qf0, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u % 3][1], qf1, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u % 3][3], qf1, a1, 0, 0, 0);
             // masking code exists only for the last EDGE key tiles (compile-time): with NT chosen as the smallest
             // even tile count that covers S, at most the last two tiles can hold keys >= S; the causal (text) variant
             // masks everywhere.
-            if (CAUSAL || kt >= NT - EDGE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + g * 4 + r;
-                    if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int kt = 2 * u + h2;
+                f32x4 acc = h2 ? a1 : a0;
+                if (CAUSAL || kt >= NT - EDGE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + g * 4 + r;
+                        if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
+                    }
                 }
+                m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+                s[kt] = acc;
             }
-            m = fmaxf(m, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-            s[kt] = acc;
-            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // cap the K fragments the scheduler keeps in flight
+            __builtin_amdgcn_sched_barrier(0);
         }
         m = group_max(m);
+        // the first two V^T fragment groups fly under the exponentials
+        bf16x8 vr[3][4];
+        auto v_grp = [&](int u, bf16x8 (&f)[4]) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) f[dt] = img_tr_frag(vimg, il, u, dt);
+        };
+        v_grp(0, vr[0]);
+        if (NT > 2) v_grp(1, vr[1]);
         float l = 0.f;
         const float mc = m * C2;
 #pragma unroll
@@ -175,14 +201,15 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NT / 2; ++u) {
+            if (u + 2 < NT / 2) v_grp(u + 2, vr[(u + 2) % 3]);
             const bf16x8 pf = pack8(s[2 * u], s[2 * u + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg, il, u, dt), pf,
-                                                                o[dt], 0, 0, 0);
-            if (u & 1) __builtin_amdgcn_sched_barrier(0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[u % 3][dt], pf, o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q < p.S) {
             const float inv = __frcp_rn(l);
@@ -421,7 +448,8 @@ int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
 // EDGE = 2 when only the last two key tiles can be partial (S > (NT - 2) * 16), else every tile carries mask code.
 template <int NT, bool CAUSAL>
 int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
-    // measured (tools/attn_bench.py, b=512 S=316): forward is faster with 4 waves, backward with 8
+    // measured (tools/attn_bench.py, b=512 S=316): forward 4 / 5 / 6 / 8 waves = 330 / 461 / 403 / 360 us (the kernels are
+    // LDS-instruction bound, more waves only add contention); backward is faster with 8
     const bool tight = a.S > (NT - 2) * 16;
     return tight ? launch_fwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_fwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
