@@ -276,36 +276,60 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dq_kernel(MhaArgs p) {
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+        // software pipeline over the 32-key steps, as in pass B: S / dP of step u + 1 run under the exp / dS arithmetic of u
+        f32x4 sa[2][2], dp[2][2];                      // [parity of u][tile]
+        auto s_products = [&](int u, f32x4 (&sa_)[2], f32x4 (&dp_)[2]) {
+            bf16x8 kr[2][2], vr[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    kr[t][ds] = img_row_frag(kimg, il, 2 * u + t, ds);
+                    vr[t][ds] = img_row_frag(vimg, il, 2 * u + t, ds);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, d = f32x4{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[t][0], qf0, a, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[t][0], do0, d, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[t][1], qf1, a, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[t][1], do1, d, 0, 0, 0);
+                sa_[t] = a; dp_[t] = d;
+            }
+        };
+        s_products(0, sa[0], dp[0]);
+#pragma unroll
         for (int u = 0; u < NT / 2; ++u) {
+            bf16x8 ktr[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ktr[dt] = img_tr_frag(kimg, il, u, dt);
+            if (u + 1 < NT / 2) s_products(u + 1, sa[(u + 1) & 1], dp[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 ds2[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int kt = 2 * u + t;
-                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, sa, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, sa, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 0), do0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 1), do1, dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nlse);
+                    float pr = __builtin_amdgcn_exp2f(sa[u & 1][t][r] * C2 + nlse);
                     if (CAUSAL || kt >= NT - EDGE) {         // compile-time for the non-causal towers
                         const int key = kt * 16 + g * 4 + r;
                         if (key >= p.S || (CAUSAL && key > q)) pr = 0.f;
                     }
-                    ds2[t][r] = pr * (dp[r] - dl) * SCALE;
+                    ds2[t][r] = pr * (dp[u & 1][t][r] - dl);          // the 1/sqrt(d) factor is applied once, to dq
                 }
             }
             const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(kimg, il, u, dt), dsf, dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsf, dq[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q < p.S) {
             bf16_t* dqp = p.dqkv + (row_base + q) * ld + h * 64 + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dqp + dt * 16) = f32x4_to_bf16x4(dq[dt]);
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dqp + dt * 16) = f32x4_to_bf16x4(dq[dt] * SCALE);
         }
     }
 }
@@ -362,45 +386,69 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 2
+        // Software pipeline over the 32-query steps: the S / dP products of step u + 1 are issued under the exp / dS
+        // arithmetic of step u (the MFMA pipe runs them while the VALU works), and the transposed fragments of step u are
+        // requested before that arithmetic, so no step starts with an LDS round trip or waits for its own MFMAs.
+        f32x4 sa[2][2], dp[2][2];                      // [parity of u][tile]
+        auto s_products = [&](int u, f32x4 (&sa_)[2], f32x4 (&dp_)[2]) {
+            bf16x8 qr[2][2], dr[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    qr[t][ds] = img_row_frag(qimg, il, 2 * u + t, ds);
+                    dr[t][ds] = img_row_frag(doimg, il, 2 * u + t, ds);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, d = f32x4{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[t][0], kf0, a, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[t][0], vf0, d, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[t][1], kf1, a, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[t][1], vf1, d, 0, 0, 0);
+                sa_[t] = a; dp_[t] = d;
+            }
+        };
+        s_products(0, sa[0], dp[0]);
+#pragma unroll
         for (int u = 0; u < NT / 2; ++u) {
+            bf16x8 dot[4], qtr[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dot[dt] = img_tr_frag(doimg, il, u, dt); qtr[dt] = img_tr_frag(qimg, il, u, dt); }
+            if (u + 1 < NT / 2) s_products(u + 1, sa[(u + 1) & 1], dp[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 p2[2], ds2[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int qt = 2 * u + t;
-                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 0), kf0, sa, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 1), kf1, sa, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 0), vf0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 1), vf1, dp, 0, 0, 0);
                 const f32x4 nl = *(const f32x4*)(slse + qt * 16 + g * 4);
                 const f32x4 dl = *(const f32x4*)(sdel + qt * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nl[r]);
+                    float pr = __builtin_amdgcn_exp2f(sa[u & 1][t][r] * C2 + nl[r]);
                     if (CAUSAL || qt >= NT - EDGE) {
                         const int q = qt * 16 + g * 4 + r;
                         if (q >= p.S || (CAUSAL && key > q)) pr = 0.f;
                     }
                     p2[t][r] = pr;
-                    ds2[t][r] = pr * (dp[r] - dl[r]) * SCALE;
+                    ds2[t][r] = pr * (dp[u & 1][t][r] - dl[r]);       // the 1/sqrt(d) factor is applied once, to dk
                 }
             }
             const bf16x8 pf = pack8(p2[0], p2[1]);
             const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(doimg, il, u, dt), pf,
-                                                                 dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(qimg, il, u, dt), dsf,
-                                                                 dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, dk[dt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (key < p.S) {
             bf16_t* dkp = p.dqkv + (row_base + key) * ld + D + h * 64 + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *(bf16x4*)(dkp + dt * 16) = f32x4_to_bf16x4(dk[dt]);
+                *(bf16x4*)(dkp + dt * 16) = f32x4_to_bf16x4(dk[dt] * SCALE);
                 *(bf16x4*)(dkp + D + dt * 16) = f32x4_to_bf16x4(dv[dt]);
             }
         }
