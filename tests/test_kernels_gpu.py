@@ -216,7 +216,9 @@ def ref_attention(qkv, batch, S, H, causal):
 
 
 @pytest.mark.parametrize("batch,S,H,causal", [(2, 31, 12, False), (3, 316, 12, False), (2, 77, 8, True), (2, 50, 12, False),
-                                              (1, 16, 1, False), (2, 306, 12, False), (3, 20, 8, True)])
+                                              (1, 16, 1, False), (2, 306, 12, False), (3, 20, 8, True),
+                                              # S > 384: streaming kernels (YAML-default stride [16,16] at T=1000 -> 428)
+                                              (2, 428, 12, False), (1, 645, 4, False), (2, 450, 2, True), (1, 1213, 2, False)])
 def test_mha(ops, batch, S, H, causal):
     D = H * 64
     qkv = rnd(batch * S, 3 * D, seed=1, dtype=torch.bfloat16, scale=1.5)

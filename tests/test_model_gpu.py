@@ -88,10 +88,11 @@ def test_block_golden(M, golden, tag, D, S, b, causal):
     assert rel_err(sl["resblocks.0.mlp.c_fc.weight"].grad[::131, ::17], g["g_c_fc_w_rows"]) < 4e-2
 
 
-@pytest.mark.parametrize("D,S,b,layers", [(1024, 50, 2, 2), (768, 306, 1, 1), (256, 17, 3, 1)])
+@pytest.mark.parametrize("D,S,b,layers", [(1024, 50, 2, 2), (768, 306, 1, 1), (256, 17, 3, 1), (768, 428, 1, 1)])
 def test_backbone_other_widths_match_oracle(M, D, S, b, layers):
     """Widths beyond the two reference towers (ViT-L's 1024 = BASELINE configs[4], heads = width // 64, val.py:474) and the
-    shipped-default token count (T=1000 -> S=306): HIP stack against the CPU restatement."""
+    shipped-default token counts (T=1000: S=306 with the scripts' stride [16,24], S=428 with the YAML's [16,16], which takes the
+    streaming attention kernels): HIP stack against the CPU restatement."""
     from oracle import ref_cpu as R
     bb = M.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=D, ctx_len=None)
     w = gen.det_weights(f"wide/{D}", gen.backbone_shapes(D, layers))

@@ -3,7 +3,7 @@
 //
 // gfx950 design.  Sequences on this path are short (S <= 316 audio tokens, <= 77 text tokens), so one
 // head's whole K and V (<= 40 KiB each in bf16) live in LDS: one workgroup per (batch, head), no online
-// softmax, no second pass over keys.  All products run on v_mfma_f32_16x16x32_bf16 with the QUERY on the
+// softmax, no second pass over keys (S > 384 takes the streaming variants at the end of the file).  All products run on v_mfma_f32_16x16x32_bf16 with the QUERY on the
 // MFMA column (lane & 15):
 //     S^T tile  = K_tile . Q^T          (A = K rows from LDS by ds_read_b128, B = Q rows from registers)
 //     O^T tile  = V^T . P^T             (A = V^T by ds_read_b64_tr_b16 transposed reads, B = P in place)
@@ -455,6 +455,300 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming variants for sequences that do not fit the resident scheme (S > 384: e.g. the YAML default stride [16,16] at
+// T = 1000 gives S = 428; longer clips go beyond).  Same products, same fragment layouts, but the "other" matrices pass
+// through LDS in 64-row chunks (two 16 KiB buffers, the next chunk's LDS-DMA in flight under the current chunk's
+// MFMAs) and the forward keeps a running maximum / sum (online softmax).  One workgroup = 64 rows of the "own" dimension
+// (4 waves x 16), grid = (batch * heads) x ceil(S / 64); two passes backward as above, no atomics.
+constexpr int CH = 64;                         // chunk rows
+constexpr int CH_IMG = CH * 128;               // bytes of one 64-row image
+
+__device__ __forceinline__ void dma_chunk(char* img, __amdgpu_buffer_rsrc_t rs, uint32_t ld_bytes, int row0, int wave,
+                                          int lane) {
+    // 8 blocks of 8 rows, two per wave; the swizzle depends on the row inside the image, the source row is row0 + that
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int blk = wave * 2 + i;
+        const int r = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ img_swz(r);
+        lds_dma16(rs, img + blk * 1024, (uint32_t)(row0 + r) * ld_bytes + (uint32_t)c * 16, 0);
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void mha_fwd_stream_kernel(MhaArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * CH_IMG];   // [buffer][K | V]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nqb = (p.S + CH - 1) / CH;
+    const int bh = blockIdx.x / nqb, qblk = blockIdx.x % nqb;
+    const int b = bh / p.H, h = bh % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    const auto rsK = uniform_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0);
+    const auto rsV = uniform_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0);
+
+    const int qcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    const int q = qblk * CH + wave * 16 + qcol;
+    const bf16_t* qp = base + (int64_t)(q < p.S ? q : p.S - 1) * ld + 8 * g;
+    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    const int nch = CAUSAL ? qblk + 1 : (p.S + CH - 1) / CH;    // causal: keys beyond the block's last query never count
+
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dma_chunk(smem, rsK, ld * 2, 0, wave, lane);
+    dma_chunk(smem + CH_IMG, rsV, ld * 2, 0, wave, lane);
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();                                   // chunk c has landed; every wave is done with chunk c - 1
+        if (c + 1 < nch) {
+            char* nb = smem + ((c + 1) & 1) * 2 * CH_IMG;
+            dma_chunk(nb, rsK, ld * 2, (c + 1) * CH, wave, lane);
+            dma_chunk(nb + CH_IMG, rsV, ld * 2, (c + 1) * CH, wave, lane);
+        }
+        const char* kimg = smem + (c & 1) * 2 * CH_IMG;
+        const char* vimg = kimg + CH_IMG;
+        f32x4 sc[4];
+        float mc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = c * CH + kt * 16 + g * 4 + r;
+                if (key >= p.S || (CAUSAL && key > q)) acc[r] = -INFINITY;
+            }
+            mc = fmaxf(mc, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+            sc[kt] = acc;
+        }
+        mc = group_max(mc);
+        const float mn = fmaxf(m, mc);                     // finite from the first chunk on (key 0 is never masked)
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * C2);
+        const float mnc = mn * C2;
+        float lc = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sc[kt][r] * C2 - mnc);
+                sc[kt][r] = e;
+                lc += e;
+            }
+        l = l * alpha + group_sum(lc);
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 pf = pack8(sc[2 * u], sc[2 * u + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg, il, u, dt), pf, o[dt], 0, 0, 0);
+        }
+    }
+    if (q < p.S) {
+        const float inv = __frcp_rn(l);
+        bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
+        if (g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void mha_bwd_dq_stream_kernel(MhaArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * CH_IMG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nqb = (p.S + CH - 1) / CH;
+    const int bh = blockIdx.x / nqb, qblk = blockIdx.x % nqb;
+    const int b = bh / p.H, h = bh % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    const auto rsK = uniform_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0);
+    const auto rsV = uniform_rsrc(base + 2 * D, lim > (uint32_t)(D * 4) ? lim - D * 4 : 0);
+    dma_chunk(smem, rsK, ld * 2, 0, wave, lane);
+    dma_chunk(smem + CH_IMG, rsV, ld * 2, 0, wave, lane);
+
+    const int qcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    const int q = qblk * CH + wave * 16 + qcol;
+    const int qrow = q < p.S ? q : p.S - 1;
+    const bf16_t* qp = base + (int64_t)qrow * ld + 8 * g;
+    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    const int64_t orow = (row_base + qrow) * D + h * 64 + 8 * g;
+    const bf16x8 do0 = *(const bf16x8*)(p.dout + orow), do1 = *(const bf16x8*)(p.dout + orow + 32);
+    const bf16x8 o0 = *(const bf16x8*)(p.out + orow), o1 = *(const bf16x8*)(p.out + orow + 32);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)do0[e] * (float)o0[e] + (float)do1[e] * (float)o1[e];
+    dl = group_sum(dl);
+    const int64_t stat = ((int64_t)b * p.H + h) * p.S + qrow;
+    const float nlse = -p.lse[stat] * LOG2E;
+    if (g == 0 && q < p.S) p.delta[stat] = dl;
+    const int nch = CAUSAL ? qblk + 1 : (p.S + CH - 1) / CH;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();
+        if (c + 1 < nch) {
+            char* nb = smem + ((c + 1) & 1) * 2 * CH_IMG;
+            dma_chunk(nb, rsK, ld * 2, (c + 1) * CH, wave, lane);
+            dma_chunk(nb + CH_IMG, rsV, ld * 2, (c + 1) * CH, wave, lane);
+        }
+        const char* kimg = smem + (c & 1) * 2 * CH_IMG;
+        const char* vimg = kimg + CH_IMG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 ds2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = 2 * u + t;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 0), qf0, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 0), do0, dp, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg, il, kt, 1), qf1, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg, il, kt, 1), do1, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = c * CH + kt * 16 + g * 4 + r;
+                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nlse);
+                    if (key >= p.S || (CAUSAL && key > q)) pr = 0.f;
+                    ds2[t][r] = pr * (dp[r] - dl);
+                }
+            }
+            const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(kimg, il, u, dt), dsf, dq[dt], 0, 0, 0);
+        }
+    }
+    if (q < p.S) {
+        bf16_t* dqp = p.dqkv + (row_base + q) * ld + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(dqp + dt * 16) = f32x4_to_bf16x4(dq[dt] * SCALE);
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void mha_bwd_dkv_stream_kernel(MhaArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * CH_IMG];
+    __shared__ float sstat[2][2][CH];                      // [buffer][-lse*log2e | delta][query in chunk]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkb = (p.S + CH - 1) / CH;
+    const int bh = blockIdx.x / nkb, kblk = blockIdx.x % nkb;
+    const int b = bh / p.H, h = bh % p.H;
+    const int D = p.H * 64, ld = 3 * D;
+    const int64_t row_base = (int64_t)b * p.S;
+    const bf16_t* base = p.qkv + row_base * ld + h * 64;
+    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
+    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
+    const bf16_t* dobase = p.dout + row_base * D + h * 64;
+    const int64_t remain_o = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
+    const uint32_t lim_o = (uint32_t)(remain_o > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain_o);
+    const auto rsQ = uniform_rsrc(base, lim);
+    const auto rsO = uniform_rsrc(dobase, lim_o);
+    const float* lse_h = p.lse + ((int64_t)b * p.H + h) * p.S;
+    const float* del_h = p.delta + ((int64_t)b * p.H + h) * p.S;
+    const int c0 = CAUSAL ? kblk : 0;                      // causal: queries before the block's first key never see it
+    const int nch = (p.S + CH - 1) / CH;
+    auto load_chunk = [&](int c) {
+        char* nb = smem + (c & 1) * 2 * CH_IMG;
+        dma_chunk(nb, rsQ, ld * 2, c * CH, wave, lane);
+        dma_chunk(nb + CH_IMG, rsO, D * 2, c * CH, wave, lane);
+        if (threadIdx.x < CH) {
+            const int qq = c * CH + threadIdx.x;
+            sstat[c & 1][0][threadIdx.x] = qq < p.S ? -lse_h[qq] * LOG2E : 0.f;
+            sstat[c & 1][1][threadIdx.x] = qq < p.S ? del_h[qq] : 0.f;
+        }
+    };
+    load_chunk(c0);
+
+    const int kcol = lane & 15, g = lane >> 4;
+    const ImgLane il = img_lane(lane);
+    const int key = kblk * CH + wave * 16 + kcol;
+    const bf16_t* kp = base + (int64_t)(key < p.S ? key : p.S - 1) * ld + D + 8 * g;
+    const bf16x8 kf0 = *(const bf16x8*)kp, kf1 = *(const bf16x8*)(kp + 32);
+    const bf16x8 vf0 = *(const bf16x8*)(kp + D), vf1 = *(const bf16x8*)(kp + D + 32);
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int c = c0; c < nch; ++c) {
+        __syncthreads();
+        if (c + 1 < nch) load_chunk(c + 1);
+        const char* qimg = smem + (c & 1) * 2 * CH_IMG;
+        const char* doimg = qimg + CH_IMG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 p2[2], ds2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * u + t;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 0), kf0, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 0), vf0, dp, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg, il, qt, 1), kf1, sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(doimg, il, qt, 1), vf1, dp, 0, 0, 0);
+                const f32x4 nl = *(const f32x4*)(&sstat[c & 1][0][qt * 16 + g * 4]);
+                const f32x4 dl = *(const f32x4*)(&sstat[c & 1][1][qt * 16 + g * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = c * CH + qt * 16 + g * 4 + r;
+                    float pr = __builtin_amdgcn_exp2f(sa[r] * C2 + nl[r]);
+                    if (qq >= p.S || (CAUSAL && key > qq)) pr = 0.f;
+                    p2[t][r] = pr;
+                    ds2[t][r] = pr * (dp[r] - dl[r]);
+                }
+            }
+            const bf16x8 pf = pack8(p2[0], p2[1]);
+            const bf16x8 dsf = pack8(ds2[0], ds2[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(doimg, il, u, dt), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(qimg, il, u, dt), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (key < p.S) {
+        bf16_t* dkp = p.dqkv + (row_base + key) * ld + D + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *(bf16x4*)(dkp + dt * 16) = f32x4_to_bf16x4(dk[dt] * SCALE);
+            *(bf16x4*)(dkp + D + dt * 16) = f32x4_to_bf16x4(dv[dt]);
+        }
+    }
+}
+
+template <bool CAUSAL, bool BWD>
+int32_t launch_stream(const MhaArgs& a, hipStream_t s) {
+    const int64_t grid = (int64_t)a.batch * a.H * ((a.S + CH - 1) / CH);
+    VIPANT_REQUIRE(grid < (1ll << 31), VIPANT_EBADSHAPE, "mha: too many workgroups");
+    if (!BWD) {
+        hipLaunchKernelGGL(mha_fwd_stream_kernel<CAUSAL>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(mha_bwd_dq_stream_kernel<CAUSAL>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        VIPANT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mha_bwd_dkv_stream_kernel<CAUSAL>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    }
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
 int attn_waves() {
     static const int nw = getenv("VIPANT_ATTN_WAVES") ? atoi(getenv("VIPANT_ATTN_WAVES")) : 8;
     return nw == 4 ? 4 : 8;
@@ -512,13 +806,14 @@ int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
 
 template <bool CAUSAL, bool BWD>
 int32_t dispatch(const MhaArgs& a, hipStream_t s) {
+    static const bool force_stream = getenv("VIPANT_ATTN_STREAM") && atoi(getenv("VIPANT_ATTN_STREAM")) == 1;   // tests / timing
+    if (force_stream) return launch_stream<CAUSAL, BWD>(a, s);
 #define VIPANT_MHA_CASE(NT) \
     if (a.S <= NT * 16) return BWD ? launch_bwd<NT, CAUSAL>(a, s) : launch_fwd<NT, CAUSAL>(a, s);
     VIPANT_MHA_CASE(2) VIPANT_MHA_CASE(4) VIPANT_MHA_CASE(6) VIPANT_MHA_CASE(10) VIPANT_MHA_CASE(14)
     VIPANT_MHA_CASE(20) VIPANT_MHA_CASE(24)
 #undef VIPANT_MHA_CASE
-    vipant_set_error("mha: sequence length %d > 384 is not supported by the resident-K/V kernel", a.S);
-    return VIPANT_EBADSHAPE;
+    return launch_stream<CAUSAL, BWD>(a, s);       // S > 384: chunks of the other dimension streamed through LDS
 }
 
 int32_t check(const void* qkv, int64_t batch, int64_t S, int64_t H) {
