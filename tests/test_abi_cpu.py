@@ -53,8 +53,10 @@ def test_bad_arguments_are_reported_not_executed():
     from vipant_amd import _ffi
     with pytest.raises(_ffi.VipantError, match="K%64"):
         _ffi.call("vipant_gemm_nt", 16, 100, 16, 100, 16, 64, None, None, 1.0, 4, 64, 100, 0, None)
-    with pytest.raises(_ffi.VipantError, match="sequence length"):
-        _ffi.call("vipant_mha_fwd", 16, 16, 16, 1, 1000, 12, 0, None)
+    with pytest.raises(_ffi.VipantError, match="empty problem"):
+        _ffi.call("vipant_mha_fwd", 16, 16, 16, 1, 0, 12, 0, None)
+    with pytest.raises(_ffi.VipantError, match="16-byte aligned"):
+        _ffi.call("vipant_mha_fwd", 8, 16, 16, 1, 100, 12, 0, None)
     with pytest.raises(_ffi.VipantError, match="workspace"):
         _ffi.call("vipant_infonce_fwd_bwd", 16, 16, 16, 0.0, 16, None, None, None, 1.0, 64, 512, 0, 64, None, 0, None)
 
