@@ -90,6 +90,33 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)p);
 }
 
+// The same transposed read issued through inline asm.  hipcc treats the builtin above as "may alias any LDS-DMA in flight"
+// and puts `s_waitcnt vmcnt(0)` in front of it, which makes a kernel that has just issued the NEXT stage's LDS-DMA wait for
+// it before reading the CURRENT stage (plain ds_read_b128 loads do not have this problem).  The asm form is invisible to that
+// analysis, so the caller owns both waits: the LDS-DMA that filled the bytes must be complete (vmcnt + barrier), and the result
+// must be awaited with lds_raw_wait<N>() + lds_raw_use() before it is consumed.
+typedef int v2i32_t __attribute__((ext_vector_type(2)));
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(LDS_AS const char*)p; }
+__device__ __forceinline__ bf16x8 lds_read_tr16_pair_raw(uint32_t addr_lo, uint32_t addr_hi) {
+    v2i32_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr_lo));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(addr_hi));
+    v4i32_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    return __builtin_bit_cast(bf16x8, r);
+}
+// wait until at most N LDS operations of this wave are outstanding (they complete in order)
+template <int N>
+__device__ __forceinline__ void lds_raw_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// order a fragment's consumers behind the preceding lds_raw_wait (asm volatile statements keep their order; this one
+// "produces" the value the MFMA reads)
+__device__ __forceinline__ void lds_raw_use(bf16x8& f) {
+    v4i32_t t = __builtin_bit_cast(v4i32_t, f);
+    asm volatile("" : "+v"(t));
+    f = __builtin_bit_cast(bf16x8, t);
+}
+
 // XCD-aware bijective remap of a linear block id: blocks id, id+8, ... share an XCD, give each XCD a
 // contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same L2.
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -90,13 +90,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
         }
     // Column block cb (16 columns = 2 chunks) adds (2*cb) to the logical chunk; since tn_swz only touches
     // bits 1..3 and 2*cb has bit 0 clear, (c0 + 2cb) ^ s == (c0 ^ s) ^ (2cb)  ->  XOR the byte offset with cb<<5.
-    auto frag = [&](const char* tile, int ks, int cb) -> bf16x8 {
-        const bf16x4 lo = lds_read_tr16(tile + (rdoff[ks][0] ^ (uint32_t)(cb << 5)));
-        const bf16x4 hi = lds_read_tr16(tile + (rdoff[ks][1] ^ (uint32_t)(cb << 5)));
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
+    const uint32_t lds0 = lds_offset(smem);
+    auto frag = [&](uint32_t tile, int ks, int cb) -> bf16x8 {      // raw (asm) reads: see lds_read_tr16_pair_raw in common.h
+        return lds_read_tr16_pair_raw(tile + (rdoff[ks][0] ^ (uint32_t)(cb << 5)), tile + (rdoff[ks][1] ^ (uint32_t)(cb << 5)));
     };
 
     f32x4 acc[8][4];
@@ -126,19 +122,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
                 }
             }
             // Explicit fragment pipeline (same as the NT kernel): the B fragments of the whole K-tile first, the A
-            // fragments in a 3-deep register ring two MFMA groups ahead of their use.
+            // fragments in a 3-deep register ring two MFMA groups ahead of their use.  The transposed reads go through
+            // inline asm (the builtin would make hipcc drain the LDS-DMA of the NEXT stage, issued just above, before
+            // touching this one), so the lgkmcnt waits are explicit: LDS results return in order, a fragment = 2 reads.
+            const uint32_t tA = lds0 + (uint32_t)(cur * STAGE_BYTES), tB = tA + OP_BYTES;
             bf16x8 fq[2][4], fp[3];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fq[ks][j] = frag(sB, ks, wq * 4 + j);
-            fp[0] = frag(sA, 0, wp * 8 + 0);
-            fp[1] = frag(sA, 0, wp * 8 + 1);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 4; ++j) fq[ks][j] = frag(tB, ks, wq * 4 + j);
+            fp[0] = frag(tA, 0, wp * 8 + 0);
+            fp[1] = frag(tA, 0, wp * 8 + 1);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int ks = t >> 3, i = t & 7;
-                if (t + 2 < 16) fp[(t + 2) % 3] = frag(sA, (t + 2) >> 3, wp * 8 + ((t + 2) & 7));
+                if (t + 2 < 16) fp[(t + 2) % 3] = frag(tA, (t + 2) >> 3, wp * 8 + ((t + 2) & 7));
+                // outstanding behind fragment t: the fragments of groups t+1 and t+2 (2 reads each)
+                if (t + 2 < 16) lds_raw_wait<4>(); else if (t + 1 < 16) lds_raw_wait<2>(); else lds_raw_wait<0>();
+                lds_raw_use(fp[t % 3]);
+                if (t == 0) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lds_raw_use(fq[k2][j]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[ks][j], fp[t % 3], acc[i][j], 0, 0, 0);
