@@ -95,6 +95,10 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Make the compiler wait for a prefetched fragment HERE (before the block's output stores are issued): vmcnt counts loads and
+// stores in one in-order counter, so a wait placed after the stores would also wait for their write acknowledgements.
+__device__ __forceinline__ void settle(bf16x8& f) { lds_raw_use(f); }
+
 struct MhaArgs {
     const bf16_t* qkv; bf16_t* out; float* lse;
     const bf16_t* dout; float* delta; bf16_t* dqkv;
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
     };
     bf16x8 qn0, qn1;
     load_q(wave, qn0, qn1);
+    settle(qn0); settle(qn1);           // so that the loop header never carries a vmcnt wait (it would also cover the stores)
     for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
         const bf16x8 qf0 = qn0, qf1 = qn1;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[u % 3][dt], pf, o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        settle(qn0); settle(qn1);          // next block's query fragments have arrived; the stores below drain under its MFMAs
         if (q < p.S) {
             const float inv = __frcp_rn(l);
             bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
@@ -259,6 +265,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dq_kernel(MhaArgs p) {
     };
     QBlock nxt;
     load_blk(wave, nxt);
+    settle(nxt.q0); settle(nxt.q1); settle(nxt.do0); settle(nxt.do1); settle(nxt.o0); settle(nxt.o1);
+    asm volatile("" : "+v"(nxt.lse));
     for (int qb = wave; qb * 16 < p.S; qb += NW) {
         const int q = qb * 16 + qcol;
         const int qrow = q < p.S ? q : p.S - 1;
@@ -326,6 +334,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dq_kernel(MhaArgs p) {
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsf, dq[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        settle(nxt.q0); settle(nxt.q1); settle(nxt.do0); settle(nxt.do1); settle(nxt.o0); settle(nxt.o1);
+        asm volatile("" : "+v"(nxt.lse));
         if (q < p.S) {
             bf16_t* dqp = p.dqkv + (row_base + q) * ld + h * 64 + g * 4;
 #pragma unroll
@@ -377,6 +387,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
     };
     KBlock knxt;
     load_kv(wave, knxt);
+    settle(knxt.k0); settle(knxt.k1); settle(knxt.v0); settle(knxt.v1);
     for (int kb = wave; kb * 16 < p.S; kb += NW) {
         const int key = kb * 16 + kcol;
         const KBlock kcur = knxt;
@@ -444,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        settle(knxt.k0); settle(knxt.k1); settle(knxt.v0); settle(knxt.v1);
         if (key < p.S) {
             bf16_t* dkp = p.dqkv + (row_base + key) * ld + D + h * 64 + g * 4;
 #pragma unroll

@@ -89,15 +89,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNT p) {
 // Stage the 256x256 accumulator tile through a 64 KiB LDS area and write it out as whole rows (16 B per lane),
 // applying the epilogue on the way.  Uses raw s_barrier + lgkmcnt waits only, so LDS-DMA prefetches in flight survive.
 template <int EPI>
-__device__ __forceinline__ void staged_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], char* stg, int cm0, int cn0, int wm,
-                                                int wn, int frow, int fq, int tid) {
-    f32x4 bv[4];
+__device__ __forceinline__ void load_bias(const GemmNT& p, int cn0, int wn, int fq, f32x4 (&bv)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n4 = cn0 + wn * 64 + j * 16 + fq * 4;
         bv[j] = (EPI != VIPANT_EPI_DQUICKGELU && p.bias != nullptr && n4 < p.N) ? *(const f32x4*)(p.bias + n4)
                                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void staged_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], char* stg, int cm0, int cn0, int wm,
+                                                int wn, int frow, int fq, int tid, const f32x4 (&bv)[4]) {
     if (EPI == VIPANT_EPI_RESIDUAL_F32) {
         // fp32 tile: 4 rounds of 64 rows x 1 KiB; 16-B chunk index XOR (row & 7)
 #pragma unroll
@@ -287,11 +290,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
         // both stages are free now: prefetch the next tile's first K-step into stage 0, stage the output through stage 1
         const int cm0 = m0, cn0 = n0;
         const int next = tile + G;
+        // the bias is fetched BEFORE the next tile's LDS-DMA is issued: vmcnt retires in issue order, so a bias load issued
+        // after the prefetch would make the epilogue wait for the prefetch to land before it can start
+        f32x4 bv[4];
+        load_bias<EPI>(p, cn0, wn, fq, bv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));      // ... and awaited here, while nothing else is in flight
         if (next < ntiles) {
             tile_rsrc(next, rsA, rsB, m0, n0);
             stage_load(rsA, rsB, 0, 0);
         }
-        staged_epilogue<EPI>(p, acc, smem + STAGE_BYTES, cm0, cn0, wm, wn, frow, fq, tid);
+        staged_epilogue<EPI>(p, acc, smem + STAGE_BYTES, cm0, cn0, wm, wn, frow, fq, tid, bv);
         tile = next;
     }
 }
