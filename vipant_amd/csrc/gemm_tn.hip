@@ -22,7 +22,7 @@ struct GemmTN {
     int M, P, Q;
     int splits, kt_per_split;
     int direct;   // 1: write straight into C (single split, no accumulate)
-    float* colsum;   // optional [splits][ntp*256]: per-split column sums of A (bias gradient of the same Linear)
+    float* colsum;   // optional [splits * ntq][ntp*256]: partial column sums of A (bias gradient of the same Linear)
 };
 
 __device__ __forceinline__ int tn_swz(int m) { return ((m & 3) | (((m >> 3) & 1) << 2)) << 1; }
@@ -103,9 +103,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
 
     // Column sums of A over the token dimension ride along: the A tile is in LDS anyway.  Thread t owns column
     // (t & 255) and the rows of half (t >> 8) of every K-tile; only the workgroups of the first Q tile do it.
-    const bool do_colsum = p.colsum != nullptr && tq == 0;
-    const int cs_col = tid & 255, cs_half = tid >> 8;
-    float cs_acc = 0.f;
+    // Column sums of A ride along.  The ntq workgroups that share an A tile take turns (K-tile kt belongs to workgroup
+    // kt % ntq), and a thread sums 8 columns (one 16-B chunk) of 4 rows per K-tile with ds_read_b128 -- the first version
+    // (the tq == 0 workgroups alone, 32 two-byte reads per thread and K-tile) made those workgroups, and with them the
+    // whole launch, 15-25 % slower.
+    const bool do_colsum = p.colsum != nullptr;
+    const int cs_chunk = tid & 31, cs_rg = tid >> 5;
+    float cs_acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs_acc[e] = 0.f;
     if (nk > 0) {
         stage_load(0, 0);
         __syncthreads();
@@ -114,11 +120,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
             if (kt + 1 < nk) stage_load(cur ^ 1, kt + 1);
             const char* sA = smem + cur * STAGE_BYTES;
             const char* sB = sA + OP_BYTES;
-            if (do_colsum) {
-#pragma unroll 8
-                for (int mm = 0; mm < 32; ++mm) {
-                    const int m = cs_half * 32 + mm;
-                    cs_acc += (float)*(const bf16_t*)(sA + m * 512 + (((cs_col >> 3) ^ tn_swz(m)) << 4) + (cs_col & 7) * 2);
+            if (do_colsum && (kt % ntq) == tq) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int m = cs_rg + 16 * k4;
+                    const bf16x8 v = *(const bf16x8*)(sA + m * 512 + ((cs_chunk ^ tn_swz(m)) << 4));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs_acc[e] += (float)v[e];
                 }
             }
             // Explicit fragment pipeline (same as the NT kernel): the B fragments of the whole K-tile first, the A
@@ -157,10 +165,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
     }
 
     if (do_colsum) {      // all LDS reads of the loop are behind its last barrier: reuse the front of the buffer
-        float* red = (float*)smem;
-        red[tid] = cs_acc;
+        float* red = (float*)smem;                     // [16 row groups][256 columns]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[cs_rg * 256 + cs_chunk * 8 + e] = cs_acc[e];
         __syncthreads();
-        if (tid < 256) p.colsum[(int64_t)split * (ntp * TP) + p0 + tid] = red[tid] + red[tid + 256];
+        if (tid < 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += red[r * 256 + tid];
+            p.colsum[((int64_t)split * ntq + tq) * (ntp * TP) + p0 + tid] = sum;
+        }
     }
     // lane holds C[p = p0 + wp*128 + i*16 + (lane&15)][q = q0 + wq*64 + j*16 + (lane>>4)*4 + 0..3]
     const int frow = lane & 15;
@@ -205,12 +219,26 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, 
     }
 }
 
-__global__ void gemm_tn_colsum_reduce_kernel(const float* part, float* out, int P, int stride, int splits, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+// out[i] (+)= sum over the `parts` partial vectors.  64 columns per 256-thread block, 4 threads per column each taking every
+// fourth partial with independent loads in flight (a single thread walking 20-80 partials one after the other made this tiny
+// kernel 20-90 us long).
+__global__ __launch_bounds__(256) void gemm_tn_colsum_reduce_kernel(const float* part, float* out, int P, int stride, int parts,
+                                                                    int accumulate) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < P) {
+        int k = sub;
+        for (; k + 4 < parts; k += 8) { s0 += part[(int64_t)k * stride + i]; s1 += part[(int64_t)(k + 4) * stride + i]; }
+        if (k < parts) s0 += part[(int64_t)k * stride + i];
+    }
+    red[sub][c] = s0 + s1;
+    __syncthreads();
+    if (sub == 0 && i < P) {
+        const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        out[i] = accumulate ? out[i] + s : s;
+    }
 }
 
 void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
@@ -230,7 +258,7 @@ extern "C" size_t vipant_gemm_tn_workspace_bytes(int64_t M, int64_t P, int64_t Q
     int splits, per;
     plan(M, P, Q, &splits, &per);
     return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float) +
-           (size_t)splits * (size_t)ceil_div(P, TP) * TP * sizeof(float);
+           (size_t)splits * (size_t)ceil_div(Q, TQ) * (size_t)ceil_div(P, TP) * TP * sizeof(float);
 }
 
 extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C,
@@ -275,8 +303,8 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
         VIPANT_LAUNCH_CHECK();
     }
     if (a_colsum != nullptr) {
-        hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s,
-                           (const float*)cs_part, a_colsum, (int)P, (int)(ceil_div(P, TP) * TP), splits, accumulate);
+        hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 64)), dim3(256), 0, s,
+                           (const float*)cs_part, a_colsum, (int)P, (int)(ceil_div(P, TP) * TP), (int)(splits * ceil_div(Q, TQ)), accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;
