@@ -100,7 +100,8 @@ def test_gemm_nt_fused_epilogues(ops):
     assert_close(out, ref, 1e-2, 2e-2, "dquickgelu")
 
 
-@pytest.mark.parametrize("M,N,K", [(4100, 2304, 768), (5000, 200, 64), (4096, 3072, 128), (6001, 776, 1024)])
+@pytest.mark.parametrize("M,N,K", [(4100, 2304, 768), (5000, 200, 64), (4096, 3072, 128), (6001, 776, 1024),
+                                   (20000, 1000, 128), (66000, 256, 64)])   # >= 256 tiles with a short last round: half-tile tail kernel
 def test_gemm_nt_short_k_large_m(ops, M, N, K):
     """Short K, many row tiles per workgroup (the persistent tile walk): ragged M / N tails and all three staged epilogues."""
     a = rnd(M, K, seed=21, dtype=torch.bfloat16); b = rnd(N, K, seed=22, dtype=torch.bfloat16, scale=K ** -0.5)
