@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--mels", type=int, default=128)
     ap.add_argument("--layers", type=int, default=L)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--script", choices=["va", "at"], default="va",
+                    help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
+                         "CLIP text tower at L=77, local negatives (run_bimodal_at.sh); extra measurement, not the headline")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
 
@@ -98,6 +101,69 @@ def cpu_baseline(args, T, Fq):
                       f"{args.layers} layers), fp32 oracle, after a 2-pair warm-up; {dt:.1f} s"}
 
 
+def bench_at(args, world, rank, local_rank, dev, use_dist):
+    """AT fine-tuning step (BASELINE configs[2]): trainable audio head, frozen causal text tower, VALCELossHead(al)."""
+    from vipant_amd import _ffi
+    from vipant_amd.config import compose
+    from vipant_amd.monitor import VALMonitor
+    from vipant_amd.module import adjust_learning_rate
+    _ffi.call("vipant_device_check")
+    T, Fq, b = args.frames, args.mels, args.batch
+    ov = ("+running=trimodal monitor=VALMonitor worker=CVALP mode=ddp eval=False +model/image=vit_val +model/audio=vit_val "
+          "+model/text=transformer_val +model/loss=ce_val +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True "
+          f"running.imagine=False model.loss.va=False model.image.encoder.layers={args.layers} +running.negatives=local "
+          f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
+          f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
+          f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
+    cfg = compose(ov)
+    cfg.rank = local_rank
+    torch.manual_seed(cfg.seed)
+    mon = VALMonitor(cfg, (lambda *_: None), dev)
+    mon.total_loss = mon.total_step = mon.total_inst = 0
+    mon.start_time = time.time()
+    images, audios, text, _, _ = mon.make_batch(next(iter(mon.dataloader)))
+    text = torch.cat([text, text.new_zeros(text.shape[0], 77 - text.shape[1])], dim=1) if text.shape[1] < 77 else text
+
+    def one_step(i):
+        adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, i + 10)
+        return mon.step(images, audios, text)
+
+    for i in range(args.warmup):
+        one_step(i)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    ms = dt / args.steps * 1e3
+    S = mon.model.audio_head.misc.positional_embedding.shape[0]
+    step_flops = b * (3 * tower_fwd_flops(S, 1024, S - 1, layers=args.layers)
+                      + 12 * 77 * (24 * 512 * 512 + 4 * 77 * 512) + 2 * 512 * E) + 6.0 * b * b * E
+    out = {"metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"AT fine-tuning step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-B/"
+                                  f"{args.layers}L fwd+bwd + frozen CLIP text tower (L=77) fwd + InfoNCE(al) + LARS, local negatives "
+                                  "(BASELINE.json configs[2]); NOT the headline configuration",
+                      "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local"},
+           "loss": round(float(loss.detach()), 4), "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
+           "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +182,8 @@ def main():
     _ffi.call("vipant_device_check")
 
     T, Fq, b = args.frames, args.mels, args.batch
+    if args.script == "at":
+        return bench_at(args, world, rank, local_rank, dev, use_dist)
     ov = ("+running=bimodal worker=CVALP mode=ddp eval=False +model/image=vit_val +model/audio=vit_val +model/text=dummy "
           "+model/loss=ce +optimizer=standard +running/audio=default model.audio.pre_encoder.in_channels=3 "
           f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={args.layers} "
