@@ -193,29 +193,29 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
         if (NT > 2) v_grp(1, vr[1]);
         float l = 0.f;
         const float mc = m * C2;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] * C2 - mc);
-                s[kt][r] = e;
-                l += e;
-            }
-        l = group_sum(l);
-
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
+        // exponentials and the second product are fused per 32-key step: the MFMAs of step u run on the matrix pipe while
+        // the VALU works on the exponentials of step u + 1
 #pragma unroll
         for (int u = 0; u < NT / 2; ++u) {
             if (u + 2 < NT / 2) v_grp(u + 2, vr[(u + 2) % 3]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[2 * u + t][r] * C2 - mc);
+                    s[2 * u + t][r] = e;
+                    l += e;
+                }
             const bf16x8 pf = pack8(s[2 * u], s[2 * u + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[u % 3][dt], pf, o[dt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        l = group_sum(l);
         settle(qn0); settle(qn1);          // next block's query fragments have arrived; the stores below drain under its MFMAs
         if (q < p.S) {
             const float inv = __frcp_rn(l);
