@@ -163,11 +163,11 @@ def test_image_head_golden(M, golden):
     assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
 
 
-@pytest.mark.parametrize("tag,L,b", [("L2", 2, 8), ("L12", 12, 32)])
-def test_end_to_end_golden(M, golden, tag, L, b):
-    """cfg1-shaped VA step (256x64 spectrograms, precomputed image embeddings): features, InfoNCE loss, gradients."""
+@pytest.mark.parametrize("tag,L,b,T,Fq", [("L2", 2, 8, 256, 64), ("L12", 12, 32, 256, 64), ("T1000", 2, 4, 1000, 128)])
+def test_end_to_end_golden(M, golden, tag, L, b, T, Fq):
+    """VA step on precomputed image embeddings at the cfg1 shape (256x64 spectrograms) and at the shipped default spectrogram
+    size (1000 x 128 -> S = 306): features, InfoNCE loss, gradients against the reference's own outputs."""
     g = golden(f"e2e_{tag}")
-    T, Fq = 256, 64
     head = M.build_audio_head(audio_cfg(T, Fq, L))
     S = head.misc.positional_embedding.shape[0]
     head.load_state_dict(gen.det_weights(f"e2e/{tag}", gen.vit_head_shapes(768, L, 512, S)), strict=True)

@@ -114,12 +114,11 @@ def test_image_head(golden):
     close(feat, g["feat"])
 
 
-@pytest.mark.parametrize("tag,L,b", [("L2", 2, 8), ("L12", 12, 32)])
-def test_end_to_end(golden, tag, L, b):
+@pytest.mark.parametrize("tag,L,b,T,Fq", [("L2", 2, 8, 256, 64), ("L12", 12, 32, 256, 64), ("T1000", 2, 4, 1000, 128)])
+def test_end_to_end(golden, tag, L, b, T, Fq):
     g = golden(f"e2e_{tag}")
-    T, Fq = 256, 64
     stride, S, pr = R.vit_position_resolution([T, Fq], 32, [16, 24])
-    assert S == int(g["S"]) == 31
+    assert S == int(g["S"]) == (31 if T == 256 else 306)
     w = {k: v.requires_grad_() for k, v in gen.det_weights(f"e2e/{tag}", gen.vit_head_shapes(768, L, 512, S)).items()}
     assert sum(v.numel() for v in w.values()) == int(g["n_params"])
     aud = gen.det_randn(f"e2e/{tag}/aud", (b, 1, T, Fq))
