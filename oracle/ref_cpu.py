@@ -329,6 +329,16 @@ def retrieval_report(x1s: Tensor, x2s: Tensor, ids=None, gold_file=None) -> str:
     return f"{stats}{p12} {p21} @ {n1}{ref}"
 
 
+def zero_shot_report(audios: Tensor, labels: Tensor, text: Tensor, label_map=None) -> str:
+    """cvap/module/decoder/loss_head.py:371-407 -- the zero-shot branch of ClassificationHead.report."""
+    ind = (audios @ text.t()).argsort(descending=True)
+    predictions = ind[:, :1]
+    if isinstance(label_map, dict):
+        predictions = torch.tensor([label_map[x] for x in predictions.flatten().tolist()]).view(predictions.shape)
+    precision = (predictions == labels.unsqueeze(-1)).sum() / audios.shape[0] * 100.0
+    return f"A->T: p1 = {precision:2.2f} @ {audios.shape[0]}"
+
+
 # --------------------------------------------------------------------------- worker glue
 def cvalp_forward(images, audios, text, *, image_sd=None, audio_sd=None, text_sd=None,
                   audio_cfg=None, image_cfg=None, text_cfg=None, loss="ce", scales=None,

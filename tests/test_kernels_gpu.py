@@ -401,3 +401,17 @@ def test_retrieval_report_goldens(golden):
     lh(3.0 * x1, 0.5 * h2)
     assert lh.report() == str(g["report_hard"])
 
+
+def test_zero_shot_report_golden(golden):
+    """Zero-shot classification report (ClassificationHead.report with text prompts) against the reference's string."""
+    from vipant_amd import module as M
+    g = golden("report_protocols")
+    prompts = gen.det_randn("zs/text", (50, 512)); prompts = prompts / prompts.norm(dim=-1, keepdim=True)
+    lab = (torch.arange(200) * 7) % 50
+    feats = prompts[lab] + 7.0 * gen.det_randn("zs/noise", (200, 512)) / 512 ** 0.5
+    feats = feats / feats.norm(dim=-1, keepdim=True)
+    perm = {i: (i * 3) % 50 for i in range(50)}
+    assert M.zero_shot_report(feats.to(DEV), lab.to(DEV), prompts.to(DEV)) == str(g["zero_shot"])
+    mapped = torch.tensor([perm[int(v)] for v in lab])
+    assert M.zero_shot_report(feats.to(DEV), mapped.to(DEV), prompts.to(DEV), label_map=perm) == str(g["zero_shot_mapped"])
+

@@ -195,3 +195,18 @@ def test_report_protocols(golden):
     assert R.retrieval_report(x1, h2, ids=names, gold_file=gold) == str(g["report_gold"])
     assert R.retrieval_report(x1[:7], h2[:9]) == str(g["report_mismatch"])
 
+
+def _zero_shot_inputs():
+    prompts = gen.det_randn("zs/text", (50, 512)); prompts = prompts / prompts.norm(dim=-1, keepdim=True)
+    lab = (torch.arange(200) * 7) % 50
+    feats = prompts[lab] + 7.0 * gen.det_randn("zs/noise", (200, 512)) / 512 ** 0.5
+    return feats / feats.norm(dim=-1, keepdim=True), lab, prompts, {i: (i * 3) % 50 for i in range(50)}
+
+
+def test_zero_shot_report(golden):
+    g = golden("report_protocols")
+    feats, lab, prompts, perm = _zero_shot_inputs()
+    assert R.zero_shot_report(feats, lab, prompts) == str(g["zero_shot"])
+    mapped = torch.tensor([perm[int(v)] for v in lab])
+    assert R.zero_shot_report(feats, mapped, prompts, label_map=perm) == str(g["zero_shot_mapped"])
+

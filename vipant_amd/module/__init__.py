@@ -11,7 +11,7 @@ from .heads import (  # noqa: F401
     load_pos_embedding,
 )
 from .loss_head import (  # noqa: F401
-    LOSS_HEADS_REGISTRY, build_loss_head, LossHead, CELossHead, VALCELossHead, DummyLossHead,
+    LOSS_HEADS_REGISTRY, build_loss_head, LossHead, CELossHead, VALCELossHead, DummyLossHead, zero_shot_report,
 )
 
 LOSS_HEADS_REGISTRY._do_register("DummyHead", DummyLossHead)

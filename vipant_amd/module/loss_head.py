@@ -157,6 +157,25 @@ class LossHead(nn.Module):
         return f"{msg}{p_12} {p_21} @ {n1}{ref}"
 
 
+def zero_shot_report(audios, labels, text, label_map=None) -> str:
+    """Zero-shot classification report: the `text is not None` branch of ClassificationHead.report
+    (cvap/module/decoder/loss_head.py:371-407), as used by cvap/monitor/esc50_clf.py:260-325.
+
+    audios [n, E] audio features, text [c, E] one feature per class prompt, labels int [n]; the prediction is the
+    arg-max prompt (mapped through `label_map` when prompts and labels use different ids).  The reference sorts all of
+    `audios @ text.t()`; here the arg-max comes from the fused retrieval kernel (`top1`), nothing n x c is stored."""
+    audios, text = audios.detach().float().contiguous(), text.detach().float().contiguous()
+    n = audios.shape[0]
+    gold = torch.zeros((n,), dtype=torch.int32)
+    _, top1 = ops.retrieval_ranks(audios, text, gold, want_top1=True)
+    predictions = top1.long()
+    if isinstance(label_map, dict):
+        predictions = torch.tensor([label_map[x] for x in predictions.tolist()], device=predictions.device)
+    labels = torch.as_tensor(labels, device=predictions.device).long()
+    precision = (predictions == labels).sum() / n * 100.      # float32 tensor, as in the reference
+    return f"A->T: p1 = {precision:2.2f} @ {n}"
+
+
 @LOSS_HEADS_REGISTRY.register()
 class CELossHead(LossHead):
     """Symmetric InfoNCE with a learnable temperature (cvap/module/decoder/loss_head.py:246-284)."""
