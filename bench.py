@@ -175,7 +175,7 @@ def main():
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from vipant_amd import _ffi, ops, parallel
+    from vipant_amd import _ffi, ops
     from vipant_amd.config import compose
     from vipant_amd.monitor import VAMonitor
     from vipant_amd.module import adjust_learning_rate
