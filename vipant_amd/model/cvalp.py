@@ -8,6 +8,7 @@ implied are provided by the feature all-gather inside the loss head (vipant_amd.
 from __future__ import annotations
 
 import re
+import os
 from collections import OrderedDict
 
 import torch
@@ -30,8 +31,17 @@ class CVALP(nn.Module):
         kwargs = {"normalized": self.loss_head.normalized, "names": kwargs.get("names", None)}
         image_features = audio_features = text_features = None
         dummy_image = images is not None and list(images.shape[1:]) == [1, 1, 1]
+        side = None
         if images is not None and self.image_head is not None and not dummy_image:
-            image_features = self.image_head(images, **kwargs)
+            if self._frozen(self.image_head) and images.is_cuda and os.environ.get("VIPANT_TOWER_OVERLAP", "1") == "1":
+                # a frozen tower has no place in the autograd tape and no dependence on the trainable tower: it runs on a
+                # side stream, so its small launches (M = 50 b tokens, short last rounds) fill in beside the audio tower's
+                side = self._side_stream(images.device)
+                side.wait_stream(torch.cuda.current_stream(images.device))
+                with torch.cuda.stream(side), torch.no_grad():
+                    image_features = self.image_head(images, **kwargs)
+            else:
+                image_features = self.image_head(images, **kwargs)
         elif images is not None:                       # pre-computed un-normalised features
             if self.loss_head.normalized and not dummy_image:
                 images = ops.l2_normalize(images)
@@ -45,11 +55,23 @@ class CVALP(nn.Module):
             if self.loss_head.normalized and not dummy_text:
                 text = ops.l2_normalize(text)
             text_features = text
+        if side is not None:                           # join before the loss reads the image features
+            torch.cuda.current_stream(images.device).wait_stream(side)
+            image_features.record_stream(torch.cuda.current_stream(images.device))
         if dummy_image:
             image_features = None                      # "dummy images will be ignored"
         if dummy_text and text is not None:
             text_features = None
         return self.loss_head(image_features, audio_features, text_features, **kwargs)
+
+    @staticmethod
+    def _frozen(head) -> bool:
+        return not any(p.requires_grad for p in head.parameters())
+
+    def _side_stream(self, device):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def encode_image(self, image, *args, **kwargs):
         return self.image_head(image, **kwargs)
