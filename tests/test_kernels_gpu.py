@@ -415,3 +415,24 @@ def test_zero_shot_report_golden(golden):
     mapped = torch.tensor([perm[int(v)] for v in lab])
     assert M.zero_shot_report(feats.to(DEV), mapped.to(DEV), prompts.to(DEV), label_map=perm) == str(g["zero_shot_mapped"])
 
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 9, 255, 257])
+def test_infonce_tiny_and_ragged_batches(ops, B):
+    """Degenerate and ragged batch sizes (B = 1 gives loss 0 and zero gradients, as the reference's cross entropy does)."""
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(B)
+    a = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
+    t = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
+    ls = torch.tensor(2.6593)
+    a_, t_, l_ = a.to(DEV).requires_grad_(), t.to(DEV).requires_grad_(), ls.to(DEV).requires_grad_()
+    loss = ops.InfoNCEFn.apply(a_, t_, l_, None, 0, B, 1.0)
+    loss.backward()
+    ar, tr, lr = a.clone().requires_grad_(), t.clone().requires_grad_(), ls.clone().requires_grad_()
+    ref = R.ce_loss_head(ar, tr, lr, None)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4
+    scale = max(float(ar.grad.abs().max()), 1e-6)
+    assert float((a_.grad.cpu() - ar.grad).abs().max()) <= 2e-2 * scale + 1e-7
+    assert float((t_.grad.cpu() - tr.grad).abs().max()) <= 2e-2 * scale + 1e-7
+    assert abs(float(l_.grad) - float(lr.grad)) <= 1e-3 * max(abs(float(lr.grad)), 1.0)
+

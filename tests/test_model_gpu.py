@@ -114,6 +114,25 @@ def test_backbone_other_widths_match_oracle(M, D, S, b, layers):
         assert rel_err(p.grad, sdr[k].grad) < 5e-2, (k, rel_err(p.grad, sdr[k].grad))
 
 
+@pytest.mark.parametrize("b,S", [(1, 1), (1, 5), (3, 2)])
+def test_backbone_degenerate_shapes(M, b, S):
+    """One sample / one token: every kernel of the stack has to survive M = b * S far below a tile."""
+    from oracle import ref_cpu as R
+    bb = M.TransformerBackbone(NS(layers=1, skip_attn_mask=True), width=768, ctx_len=None)
+    w = gen.det_weights("tiny/768", gen.backbone_shapes(768, 1))
+    sd = {k[len("encoder."):]: v for k, v in w.items()}
+    bb.load_state_dict(sd, strict=True)
+    bb = bb.to(DEV)
+    x = gen.det_randn(f"tiny/x/{b}/{S}", (b, S, 768))
+    xg = x.to(DEV).requires_grad_()
+    y = bb(xg)
+    y.backward(torch.ones_like(y))
+    xr = x.clone().requires_grad_()
+    yr = R.transformer_backbone(xr, sd, "", 1, 768, None, True)
+    yr.backward(torch.ones_like(yr))
+    assert rel_err(y, yr.detach()) < 2e-2 and rel_err(xg.grad, xr.grad) < 4e-2
+
+
 @pytest.mark.parametrize("tag,T,Fq,b", [("256x64", 256, 64, 3), ("1024x128", 1024, 128, 2)])
 def test_pre_post_golden(M, golden, tag, T, Fq, b):
     g = golden(f"prepost_{tag}")
