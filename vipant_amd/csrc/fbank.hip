@@ -4,7 +4,8 @@
 // masks (image_audio.py:183-207).  Output is the [b, 1, T, F] fp32 spectrogram batch the audio tower consumes, so the
 // waveform never leaves the device once it is there.
 //
-// One wave per frame, four waves per workgroup, each walking four frames (the workgroup's tables serve 16 frames).  A frame is framed (snip_edges), DC-removed, pre-emphasised
+// One wave per frame PAIR (two real frames packed into one complex transform), four waves per workgroup, each walking
+// four pairs (the workgroup's tables serve 32 frames).  A frame is framed (snip_edges), DC-removed, pre-emphasised
 // (replicated first sample), windowed and zero-padded to NFFT in LDS; a radix-2 Stockham FFT (log2 NFFT passes
 // ping-ponging two LDS buffers, twiddles from sincospi -- exact at the power-of-two fractions) gives the spectrum;
 // every lane then owns mel bins lane, lane + 64, ... and sums power x weight over that filter's (contiguous)
@@ -49,7 +50,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
 
-constexpr int FPW = 4;            // frames per wave: the workgroup's tables (twiddles, window, mel weights) serve 16 frames
+constexpr int FPW = 4;            // frame PAIRS per wave: the workgroup's tables (twiddles, window, mel weights) serve 32 frames
 constexpr int MAXF = 256;         // mel bins
 
 template <int NFFT>
@@ -97,35 +98,49 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
     int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
     if (mk != nullptr) { f0 = mk[0]; f1 = mk[1]; t0 = mk[2]; t1 = mk[3]; }
 
+    // Two real frames share one complex transform: z = y_a + i y_b, and with Z = FFT(z)
+    //   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / (2i)
+    // so |X_a|^2 = ((Zr + Zr')^2 + (Zi - Zi')^2) / 4 and |X_b|^2 = ((Zi + Zi')^2 + (Zr' - Zr)^2) / 4 with Z' = Z[N-k].
+    // A wave walks FPW frame pairs (2t, 2t + 1); the FFT's LDS traffic per frame halves.
 #pragma unroll 1
     for (int it = 0; it < FPW; ++it) {
-        const int t = (blockIdx.x * FPW + it) * 4 + wave;
-        if (t >= a.T) break;
-        float* dst = a.out + ((int64_t)clip * a.T + t) * a.F;
-        const bool tmask = t >= t0 && t < t1;
-        if (t >= nframes || tmask) {                              // padding row or time-masked row: constant
-            float v = 0.f;
-            if (a.norm_std != 0.f) v = (v - a.norm_mean) / a.norm_std;
-            for (int m = lane; m < a.F; m += 64) dst[m] = (tmask || (m >= f0 && m < f1)) ? 0.f : v;
-            continue;
+        const int ta = ((blockIdx.x * FPW + it) * 4 + wave) * 2, tb = ta + 1;
+        if (ta >= a.T) break;
+        const bool live_a = ta < nframes && !(ta >= t0 && ta < t1);
+        const bool live_b = tb < a.T && tb < nframes && !(tb >= t0 && tb < t1);
+        const float padv = a.norm_std != 0.f ? (0.f - a.norm_mean) / a.norm_std : 0.f;
+        float* dst_a = a.out + ((int64_t)clip * a.T + ta) * a.F;
+        float* dst_b = dst_a + a.F;
+        if (!live_a) {                                            // padding row or time-masked row: constant
+            const bool tm = ta >= t0 && ta < t1;
+            for (int m = lane; m < a.F; m += 64) dst_a[m] = (tm || (m >= f0 && m < f1)) ? 0.f : padv;
         }
-        const float* src = a.wave + (int64_t)clip * a.wave_stride + (int64_t)t * a.shift;
-        float s = 0.f;
+        if (!live_b && tb < a.T) {
+            const bool tm = tb >= t0 && tb < t1;
+            for (int m = lane; m < a.F; m += 64) dst_b[m] = (tm || (m >= f0 && m < f1)) ? 0.f : padv;
+        }
+        if (!live_a && !live_b) continue;
+        const float* src = a.wave + (int64_t)clip * a.wave_stride + (int64_t)ta * a.shift;
+        float* raw_b = raw + NFFT;
+        float sa = 0.f, sb = 0.f;
         for (int j = lane; j < a.size; j += 64) {
-            const float x = src[j] - cmean;
-            raw[j] = x;
-            s += x;
+            const float xa = live_a ? src[j] - cmean : 0.f;
+            const float xb = live_b ? src[j + a.shift] - cmean : 0.f;
+            raw[j] = xa; raw_b[j] = xb;
+            sa += xa; sb += xb;
         }
-        s = wave_sum(s);
-        const float fmean = s / (float)a.size;
+        sa = wave_sum(sa); sb = wave_sum(sb);
+        const float ma = sa / (float)a.size, mb = sb / (float)a.size;
         wave_lds_sync();
         for (int j = lane; j < NFFT; j += 64) {
-            float y = 0.f;
+            float ya = 0.f, yb = 0.f;
             if (j < a.size) {
-                const float x = raw[j] - fmean, xp = raw[j > 0 ? j - 1 : 0] - fmean;
-                y = (x - a.preemph * xp) * win[j];
+                const int jp = j > 0 ? j - 1 : 0;
+                const float w = win[j];
+                ya = ((raw[j] - ma) - a.preemph * (raw[jp] - ma)) * w;
+                yb = ((raw_b[j] - mb) - a.preemph * (raw_b[jp] - mb)) * w;
             }
-            buf0[j] = make_float2(y, 0.f);
+            buf0[j] = make_float2(ya, yb);
         }
         wave_lds_sync();
 
@@ -166,28 +181,31 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
             wave_lds_sync();
             float2* tmp = in; in = out; out = tmp;
         }
-        // `in` holds the spectrum; bins 0 .. NFFT/2 are the one-sided part
+        // `in` holds Z; both frames' one-sided power spectra come from Z[k] and Z[N - k]
         for (int m = lane; m < a.F; m += 64) {
             const int k0 = s_start[m], len = s_len[m];
-            float e = 0.f;
-            if (nnz > 0) {
-                const float* w = wgt + s_off[m];
-                for (int k = 0; k < len; ++k) {
-                    const float2 z = in[k0 + k];
-                    e += (z.x * z.x + z.y * z.y) * w[k];
-                }
-            } else {
-                const float* w = a.banks + (int64_t)m * (NFFT / 2 + 1) + k0;
-                for (int k = 0; k < len; ++k) {
-                    const float2 z = in[k0 + k];
-                    e += (z.x * z.x + z.y * z.y) * w[k];
-                }
+            const float* w = nnz > 0 ? wgt + s_off[m] : a.banks + (int64_t)m * (NFFT / 2 + 1) + k0;
+            float ea = 0.f, eb = 0.f;
+            for (int k = 0; k < len; ++k) {
+                const float2 z = in[k0 + k], zc = in[(NFFT - (k0 + k)) & (NFFT - 1)];
+                const float ar = z.x + zc.x, ai = z.y - zc.y, br = z.y + zc.y, bi = zc.x - z.x;
+                const float wk = 0.25f * w[k];
+                ea += (ar * ar + ai * ai) * wk;
+                eb += (br * br + bi * bi) * wk;
             }
-            float v = logf(fmaxf(e, 1.1920928955078125e-07f));
-            if (a.norm_std != 0.f) v = (v - a.norm_mean) / a.norm_std;
-            dst[m] = (m >= f0 && m < f1) ? 0.f : v;
+            const bool fm = m >= f0 && m < f1;
+            if (live_a) {
+                float v = logf(fmaxf(ea, 1.1920928955078125e-07f));
+                if (a.norm_std != 0.f) v = (v - a.norm_mean) / a.norm_std;
+                dst_a[m] = fm ? 0.f : v;
+            }
+            if (live_b) {
+                float v = logf(fmaxf(eb, 1.1920928955078125e-07f));
+                if (a.norm_std != 0.f) v = (v - a.norm_mean) / a.norm_std;
+                dst_b[m] = fm ? 0.f : v;
+            }
         }
-        wave_lds_sync();                                          // the next frame overwrites both buffers
+        wave_lds_sync();                                          // the next pair overwrites both buffers
     }
 }
 
@@ -199,7 +217,7 @@ int32_t launch_fbank(const FbankArgs& a, int64_t b, hipStream_t s) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)fbank_kernel<NFFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL(fbank_kernel<NFFT>, dim3((unsigned)((a.T + 4 * FPW - 1) / (4 * FPW)), (unsigned)b), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(fbank_kernel<NFFT>, dim3((unsigned)((a.T + 8 * FPW - 1) / (8 * FPW)), (unsigned)b), dim3(256), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
