@@ -1,2 +1,2 @@
-from vipant_amd.util import *  # noqa: F401,F403
-from vipant_amd.util import seed_all_rng, setup_logger, numel, detect_nan, AverageMeter  # noqa: F401
+"""Import-path alias of the reference package name."""
+from vipant_amd.util import seed_all_rng, setup_logger  # noqa: F401

@@ -174,3 +174,55 @@ def test_patch_grid_geometry():
     assert M.position_resolution(224, 32, None) == (7, 7)
     h = M.build_audio_head(cfg_ns(1024, 128, 1))
     assert h.misc.positional_embedding.shape == (316, 768) and tuple(h.misc.position_resolution) == (63, 5)
+
+
+def test_checkpoint_round_trip_into_at_build_and_eval(tmp_path):
+    """VA pre-training checkpoint (Monitor.save: cvap/monitor/cvalp.py:302-309 format) -> the AT fine-tuning build
+    (`from_pretrained`, cvalp.py:130-215 / clip_head.py:172-191) and the eval build (cvalp.py:105-120): the stored run config
+    must come back with attribute access and the audio tower must carry the saved weights, including the re-gridded
+    positional table when the clip length changes."""
+    from vipant_amd.config import to_plain
+    from vipant_amd.model.helper import load_checkpoint
+    small = ["model.image.encoder.layers=1", "running.audio.max_len=256", "running.audio.num_mel_bins=64",
+             f"model_root={tmp_path}", f"alias_root={tmp_path}", "model_name=ck"]
+    cfg = compose(VA + small)
+    cfg.rank = 0
+    torch.manual_seed(5)
+    va = build_main_model(cfg, lambda *_: None)
+    va.build()
+    (tmp_path / "ck").mkdir()
+    torch.save({"cfg": to_plain(cfg), "model": va.collect_audio_state_dict()}, tmp_path / "ck" / "00000002.pth")   # Monitor.save
+
+    at_cfg = compose(AT + small + ["model.text.encoder.layers=1", "model_file=00000002.pth"])
+    at_cfg.rank = 0
+    local_cfg, _, audio_sd, _, loss_sd = load_checkpoint(at_cfg, lambda *_: None)
+    assert local_cfg.model.audio.resolution == [256, 64] and local_cfg.running.audio.max_len == 256
+    logs = []
+    at = build_main_model(at_cfg, logs.append)
+    at.build()
+    assert any("Initialize audio encoder from `audio_head`" in m for m in logs), logs
+    for k, v in va.audio_head.state_dict().items():
+        assert torch.equal(at.audio_head.state_dict()[k], v), k
+
+    # a longer clip at fine-tuning time: the time axis of the positional grid is re-sliced / interpolated, everything else copied
+    at_cfg = compose(AT + small + ["model.text.encoder.layers=1", "model_file=00000002.pth", "running.audio.max_len=512"])
+    at_cfg.rank = 0
+    at = build_main_model(at_cfg, lambda *_: None)
+    at.build()
+    assert at.audio_head.misc.positional_embedding.shape[0] == 31 * 2 + 1
+    k = "encoder.resblocks.0.mlp.c_fc.weight"
+    assert torch.equal(at.audio_head.state_dict()[k], va.audio_head.state_dict()[k])
+
+    ev_cfg = compose(VA + small + ["model_file=00000002.pth", "eval=True"])
+    ev_cfg.rank = 0
+    ev = build_main_model(ev_cfg, lambda *_: None)
+    ev.build()
+    assert torch.equal(ev.audio_head.state_dict()[k], va.audio_head.state_dict()[k])
+    assert torch.equal(ev.loss_head.logit_scale, va.loss_head.logit_scale)
+
+    # a file that exists but cannot be read is an error, not a silent from-scratch run
+    (tmp_path / "ck" / "broken.pth").write_bytes(b"not a checkpoint")
+    bad = compose(AT + small + ["model_file=broken.pth"])
+    bad.rank = 0
+    with pytest.raises(Exception):
+        build_main_model(bad, lambda *_: None).build()

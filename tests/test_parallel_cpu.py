@@ -62,7 +62,7 @@ def _worker(rank, world, port, out):
         ls2 = torch.tensor(2.0, requires_grad=True)
         loss_l = R.ce_loss_head(_tower(xa[sl], wa), _tower(xt[sl], wt), ls2) / world
         loss_l.backward()
-        sync.reduce_params([wa, wt, ls2])
+        sync.reduce_params([wa, wt, ls2]); sync.wait()
         res["local"] = (wa.grad.clone(), wt.grad.clone(), ls2.grad.clone())
         if rank == 0:
             torch.save(res, out)
@@ -133,14 +133,30 @@ def _bucket_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vipant_amd import parallel
+        from vipant_amd.module import adjust_learning_rate
         g = torch.Generator().manual_seed(3)
         x = torch.randn(8, 5, generator=g)
         w1 = torch.nn.Parameter(torch.randn(5, 6, generator=g)); w2 = torch.nn.Parameter(torch.randn(6, 4, generator=g))
         sync = parallel.GradSync()
         _BucketedFn.apply(x[rank * 4:rank * 4 + 4], sync, w1, w2).sum().backward()
         sync.wait()
+        res = [w1.grad.clone(), w2.grad.clone()]
+        # siamese towers sharing an encoder: the stack runs twice over the SAME parameters in one step, every run hands
+        # over its own bucket; the reduced slices of a parameter must be summed, not overwrite each other
+        w1.grad = w2.grad = None
+        y = torch.randn(8, 5, generator=g)
+        out2 = _BucketedFn.apply(x[rank * 4:rank * 4 + 4], sync, w1, w2).sum() \
+            + 2.0 * _BucketedFn.apply(y[rank * 4:rank * 4 + 4], sync, w1, w2).sum()
+        out2.backward()
+        sync.wait()
+        res += [w1.grad.clone(), w2.grad.clone()]
+        # the LR schedule follows the whole batch: per-process batch x number of replicas (lars.py:9-22 with dp's batch)
+        opt = type("O", (), {"param_groups": [{}, {}]})()
+        ocfg = type("C", (), dict(epochs=2, warmup_epoch=0, batch_size=64, lr_weight=0.2, lr_bias=0.0048))()
+        adjust_learning_rate(ocfg, opt, range(10), 0)
+        res.append(torch.tensor(opt.param_groups[0]["lr"]))
         if rank == 0:
-            torch.save((w1.grad.clone(), w2.grad.clone()), out)
+            torch.save(res, out)
     finally:
         dist.destroy_process_group()
 
@@ -149,9 +165,14 @@ def _bucket_worker(rank, world, port, out):
 def test_bucket_reduced_inside_backward_reaches_param_grad(tmp_path):
     out = str(tmp_path / "b.pt")
     mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    g1, g2 = torch.load(out)
+    g1, g2, s1, s2, lr = torch.load(out)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(8, 5, generator=g)
     w1 = torch.randn(5, 6, generator=g).requires_grad_(); w2 = torch.randn(6, 4, generator=g).requires_grad_()
     ((x @ w1) @ w2).sum().backward()
     assert torch.allclose(g1, w1.grad, atol=1e-5) and torch.allclose(g2, w2.grad, atol=1e-5)
+    y = torch.randn(8, 5, generator=g)
+    w1.grad = w2.grad = None
+    (((x @ w1) @ w2).sum() + 2.0 * ((y @ w1) @ w2).sum()).backward()
+    assert torch.allclose(s1, w1.grad, atol=1e-4) and torch.allclose(s2, w2.grad, atol=1e-4)
+    assert abs(float(lr) - (2 * 64 / 256) * 0.2) < 1e-7

@@ -53,10 +53,7 @@ def _run(rank, world, port, out, backend="gloo"):
         mon = VAMonitor(cfg, lambda *_: None, torch.device("cuda:0"))
         img, aud = _batch(B)
         sl = slice(rank * b, (rank + 1) * b)
-        adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, 1)
-        # same LR as the single-process run: the schedule scales with the PER-PROCESS batch size in the reference
-        for gparam in mon.optimizer.param_groups:
-            gparam["lr"] = gparam["lr"] * world
+        adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, 1)      # follows the whole batch: b * world
         loss = mon.step(img[sl].cuda(), aud[sl].cuda(), None)
         torch.cuda.synchronize()
         if rank == 0:
@@ -94,3 +91,84 @@ def test_rccl_call_path_single_rank_is_identity(tmp_path):
     for k in a["params"]:
         assert torch.equal(a["params"][k], b["params"][k]), k
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: AT fine-tuning, "DDP grad all-reduce only" -- every replica scores its own b-way negatives and the
+# objective is the mean over replicas of the per-replica loss (what the reference's ddp mode would compute).
+AT_OV = ("+running=trimodal monitor=VALMonitor worker=CVALP mode=ddp eval=False num_gpus=1 +model/image=vit_val "
+         "+model/audio=vit_val +model/text=transformer_val +model/loss=ce_val +optimizer=standard +running/audio=default "
+         "model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True running.imagine=False model.loss.va=False "
+         "model.image.encoder.layers=2 model.text.encoder.layers=2 running.audio.max_len=256 running.audio.num_mel_bins=64 "
+         "running.batch_size=8 running.epochs=2 running.synthetic_steps=1 running.save_epoch=False optimizer.warmup_epoch=1 "
+         "+running.negatives=local").split()
+
+
+def _run_at_local(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vipant_amd.config import compose
+        from vipant_amd.module import adjust_learning_rate
+        from vipant_amd.monitor import VALMonitor
+        cfg = compose(AT_OV)
+        cfg.rank = rank                              # the synthetic loader seeds per rank: every replica has its own batch
+        torch.cuda.set_device(0)
+        torch.manual_seed(cfg.seed)
+        mon = VALMonitor(cfg, lambda *_: None, torch.device("cuda:0"))
+        images, audios, text, _, _ = mon.make_batch(next(iter(mon.dataloader)))
+        init = {k: v.detach().cpu().clone() for k, v in mon.model.state_dict().items()}
+        adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, 1)
+        lrs = [g["lr"] for g in mon.optimizer.param_groups]
+        loss = mon.step(images, audios, text)        # the product path: nothing here rescales losses, gradients or LR
+        torch.cuda.synchronize()
+        after = {k: v.detach().cpu().clone() for k, v in mon.model.named_parameters() if v.requires_grad}
+        torch.save({"loss": float(loss.detach()), "init": init, "after": after, "lrs": lrs,
+                    "audios": audios.cpu(), "text": text.cpu()}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path):
+    """cfg3 product path (VALMonitor.step, `running.negatives=local`) on two replicas against the CPU oracle taking one
+    LARS step on  mean_r InfoNCE(audio_r, text_r).  Biases, LayerNorm parameters and logit_scale have no trust ratio
+    (lars.py:58-66), so a SUM-instead-of-mean reduction or a per-replica LR would show as a factor `world` in their update."""
+    from oracle import ref_cpu as R
+    out = str(tmp_path / "at")
+    mp.spawn(_run_at_local, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in r0["after"]:                            # replicas stay in lock-step
+        assert torch.equal(r0["after"][k], r1["after"][k]), k
+    assert not torch.equal(r0["audios"], r1["audios"])
+    lw, lb = R.adjust_learning_rate(1, epochs=2, steps_per_epoch=1, warmup_epoch=1, batch_size=16, lr_weight=0.2, lr_bias=0.0048)
+    assert abs(r0["lrs"][0] - lw) < 1e-12 and abs(r0["lrs"][1] - lb) < 1e-12
+    init = r0["init"]
+    asd = {k[len("audio_head."):]: v.clone().requires_grad_() for k, v in init.items() if k.startswith("audio_head.")}
+    tsd = {k[len("text_head."):]: v for k, v in init.items() if k.startswith("text_head.")}
+    ls = init["loss_head.loss_head_al.logit_scale"].clone().requires_grad_()
+    stride, S, pr = R.vit_position_resolution([256, 64], 32, [16, 24])
+    total, per_rank = 0.0, []
+    for r in (r0, r1):
+        lr_ = R.cvalp_forward(torch.zeros(8, 1, 1, 1), r["audios"], r["text"], audio_sd=asd, text_sd=tsd, loss="valce",
+                              scales={"al": ls}, loss_flags=dict(va=False, lv=False, al=True),
+                              audio_cfg=dict(width=768, layers=2, stride=stride, position_resolution=pr),
+                              text_cfg=dict(width=512, layers=2, ctx_len=77))
+        per_rank.append(float(lr_))
+        total = total + lr_ / 2
+    total.backward()
+    assert abs(r0["loss"] - per_rank[0]) < 5e-3 and abs(r1["loss"] - per_rank[1]) < 5e-3, (r0["loss"], r1["loss"], per_rank)
+    ref = {f"audio_head.{k}": v for k, v in asd.items()}
+    ref["loss_head.loss_head_al.logit_scale"] = ls
+    assert set(ref) == set(r0["after"])
+    worst = 0.0
+    for k, p in ref.items():
+        p_ref, _ = R.lars_step(p.detach(), p.grad, torch.zeros_like(p), lw if p.ndim > 1 else lb)
+        d_ref, d_hip = (p_ref - p.detach()).double(), (r0["after"][k] - p.detach()).double()
+        if float(d_ref.norm()) == 0.0:
+            assert float(d_hip.norm()) == 0.0, k
+            continue
+        ratio = float(d_hip.norm() / d_ref.norm())
+        assert abs(ratio - 1) < 6e-2, (k, ratio)                         # bf16 towers: a few % on a gradient norm; never 2x
+        worst = max(worst, float((d_hip - d_ref).norm() / d_ref.norm()))
+    assert worst < 0.15, worst                                           # update direction of the noisiest tensor

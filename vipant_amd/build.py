@@ -1,7 +1,8 @@
-"""Build libvipant_hip.so (gfx950) and, optionally, nothing else: `python -m vipant_amd.build`.
+"""Build libvipant_hip.so (gfx950): `python -m vipant_amd.build [--force]`.
 
 hipcc cross-compiles without a GPU; the .so stays in-tree (vipant_amd/lib/) so it travels with the repo
-snapshot to the GPU box.  Rebuilds only when a source is newer than the library.
+snapshot to the GPU box.  Every .hip file is compiled to its own object (in parallel, only when it or a header is
+newer than the object) and the objects are linked into the library.
 """
 from __future__ import annotations
 
@@ -9,31 +10,55 @@ import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libvipant_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "vipant_hip.h")]
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _older(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "vipant_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def stale() -> bool:
+    return _older(LIB, sources() + _headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [HIPCC, *FLAGS, "-o", LIB, *sources()]
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs)]
+
+    def compile_one(src):
+        cmd = [HIPCC, *CFLAGS, "-c", src, "-o", _obj(src)]
+        if verbose:
+            print("[vipant_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *[_obj(s) for s in sources()]]
     if verbose:
         print("[vipant_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -107,7 +107,9 @@ class CVALP(nn.Module):
     def _device(self):
         if not torch.cuda.is_available():       # parameter construction / state-dict surgery can be inspected on a CPU
             return torch.device("cpu")          # host; forward() on CPU tensors raises (no CPU fallback)
-        return torch.device("cuda", self.cfg.rank if self.cfg.rank >= 0 else 0)
+        # the entry point selects this process's GPU (train.py: LOCAL_RANK); `cfg.rank` is the GLOBAL rank and is only
+        # used for logging / rank-0 duties, it must not pick the device on a multi-node run
+        return torch.device("cuda", torch.cuda.current_device())
 
     def build(self, **kwargs):
         tunable_params = dict()

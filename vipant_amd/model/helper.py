@@ -15,13 +15,14 @@ def load_checkpoint(cfg, echo):
     """-> (local_cfg, image_sd, audio_sd, text_sd, loss_sd); `model` in the .pth is a 2- or 4-tuple
     (cvap/model/helper.py:10-30, save format cvap/monitor/cvalp.py:302-309)."""
     model_file = f"{cfg.model_root}/{cfg.model_name}/{cfg.model_file}"
-    try:
-        checkpoint = torch.load(model_file, map_location="cpu", weights_only=False)
-        echo(f"Loading from {model_file}")
-    except Exception:
+    if not os.path.isfile(model_file):      # the reference degrades to from-scratch when there is no file (helper.py:15-17)
         echo(f"Failed to load the checkpoint `{model_file}`")
         return (None,) * 5
-    local_cfg = checkpoint["cfg"]
+    # an existing file that cannot be unpickled is an error, not a reason to train from scratch silently (reference
+    # .pth files pickle an omegaconf DictConfig: reading them needs omegaconf importable)
+    checkpoint = torch.load(model_file, map_location="cpu", weights_only=False)
+    echo(f"Loading from {model_file}")
+    local_cfg = _as_config(checkpoint["cfg"])
     nmodule = len(checkpoint["model"])
     if nmodule == 2:
         audio_head_sd, loss_head_sd = checkpoint["model"]
@@ -30,6 +31,21 @@ def load_checkpoint(cfg, echo):
         image_head_sd, audio_head_sd, text_head_sd, loss_head_sd = checkpoint["model"]
         return local_cfg, image_head_sd, audio_head_sd, text_head_sd, loss_head_sd
     raise ValueError(f"I don't know how to parse the checkpoint: # module is {nmodule}.")
+
+
+def _as_config(obj):
+    """The stored run config with attribute access: this repo saves a plain dict (Monitor.save), the reference an
+    omegaconf DictConfig (cvap/monitor/cvalp.py:302-309)."""
+    from ..config import Config, to_config
+    if isinstance(obj, Config):
+        return obj
+    if not isinstance(obj, dict):
+        try:
+            from omegaconf import OmegaConf
+            obj = OmegaConf.to_container(obj, resolve=True)
+        except ImportError:
+            return obj
+    return to_config(obj)
 
 
 def _read_clip_state_dict(path):

@@ -6,7 +6,7 @@ import math
 
 import torch
 
-from .. import ops
+from .. import ops, parallel
 
 __all__ = ["exclude_bias_or_norm", "adjust_learning_rate", "LARS"]
 
@@ -16,10 +16,14 @@ def exclude_bias_or_norm(p):
 
 
 def adjust_learning_rate(cfg, optimizer, dataloader, step):
-    """Linear warm-up then cosine decay to 0.1 % of base; base = batch / 256 (cvap/module/lars.py:9-22)."""
+    """Linear warm-up then cosine decay to 0.1 % of base; base = batch / 256 (cvap/module/lars.py:9-22).
+
+    `cfg.batch_size` (= `running.batch_size`) is what ONE process's loader yields.  In the reference's dp mode that
+    process feeds every GPU, so it is the whole batch; with one replica per GPU the whole batch is `world` times it, and
+    the schedule follows the whole batch -- N replicas take exactly the step of one process fed the concatenated batch."""
     max_steps = cfg.epochs * len(dataloader)
     warmup_steps = int(cfg.warmup_epoch * len(dataloader))
-    base_lr = cfg.batch_size / 256
+    base_lr = cfg.batch_size * parallel.world_size() / 256
     if step < warmup_steps:
         lr = base_lr * step / warmup_steps
     else:

@@ -187,7 +187,8 @@ class CELossHead(LossHead):
         self.scale_max = cfg.scale_max or float("inf")
         self.reduce = False
         # replica groups: "global" = all-gather features, B-way negatives (reference dp semantics);
-        # "local" = per-rank negatives, gradients averaged (what the reference's ddp mode would compute)
+        # "local" = per-rank negatives, objective = mean over ranks of the per-rank loss (what the reference's ddp mode
+        # would compute): every gradient leaves the kernel scaled by 1/world and the replicas SUM-reduce
         self.negatives = kwargs.get("negatives", "global")
 
     def copy_state_dict(self, state_dict):
@@ -210,7 +211,7 @@ class CELossHead(LossHead):
         if parallel.active() and self.negatives == "global":
             x1g, x2g = parallel.all_gather_features(x1, x2)
             return ops.InfoNCEFn.apply(x1g, x2g, ls, scale_max, parallel.rank() * b, b, 1.0)
-        return ops.InfoNCEFn.apply(x1, x2, ls, scale_max, 0, b, 1.0)
+        return ops.InfoNCEFn.apply(x1, x2, ls, scale_max, 0, b, 1.0 / parallel.world_size() if parallel.active() else 1.0)
 
 
 @LOSS_HEADS_REGISTRY.register()

@@ -156,8 +156,8 @@ class GPTPostEncoder(MetaEncoder):
 
     def forward(self, x, positional_embedding=None, class_embedding=None, mask=None, normalized=False, **kwargs):
         b, L, D = x.shape
-        return ops.ReadoutFn.apply(x.reshape(b * L, D), mask, b, L, self.ln.weight, self.ln.bias, self.proj,
-                                   bool(normalized))
+        return ops.ReadoutFn.apply(x.reshape(b * L, D), mask, b, L,
+                                   *ops.no_tape((self.ln.weight, self.ln.bias, self.proj)), bool(normalized))
 
 
 def _vit_position_resolution(input_resolution, patch_size, stride):
@@ -276,8 +276,8 @@ class ViTPostEncoder(MetaEncoder):
         if require_feature:
             raise NotImplementedError("require_feature (encoder-decoder captioning) is outside the contrastive path")
         b, S, D = x.shape
-        return ops.ReadoutFn.apply(x.reshape(b * S, D), None, b, S, self.ln.weight, self.ln.bias, self.proj,
-                                   bool(normalized))
+        return ops.ReadoutFn.apply(x.reshape(b * S, D), None, b, S,
+                                   *ops.no_tape((self.ln.weight, self.ln.bias, self.proj)), bool(normalized))
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -330,5 +330,5 @@ class TransformerBackbone(MetaEncoder):
         if self.causal and S > self.ctx_len:
             raise ValueError(f"sequence length {S} exceeds ctx_len {self.ctx_len}")
         params = [p for blk in self.resblocks for p in blk.flat_params()]
-        out = ops.BackboneFn.apply(x.reshape(b * S, D), b, S, self.causal, self.grad_sync, *params)
+        out = ops.BackboneFn.apply(x.reshape(b * S, D), b, S, self.causal, self.grad_sync, *ops.no_tape(params))
         return out.view(b, S, D)

@@ -145,8 +145,8 @@ class Monitor(object):
             if self.model.loss_head is not None and self.cfg.running.get("negatives", "global") == "global":
                 skip = {id(p) for p in self.model.loss_head.parameters()}      # complete on every rank already
                 rest = [p for p in rest if id(p) not in skip]
+            self.grad_sync.reduce_params(rest)      # one more bucket behind the per-block ones already in flight
             self.grad_sync.wait()
-            self.grad_sync.reduce_params(rest)
         self.optimizer.step()
         return loss
 

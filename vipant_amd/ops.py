@@ -44,6 +44,14 @@ def _need(t: torch.Tensor, dtype, name: str):
         raise _ffi.VipantError(f"{name}: last dimension must be contiguous")
 
 
+def no_tape(params):
+    """Parameters as the autograd nodes below should see them: under torch.no_grad() (Monitor.infer, cfg.eval) nothing
+    will be differentiated, but `ctx.needs_input_grad` still reports `requires_grad` -- and `forward` itself always runs
+    with grad mode off, so it cannot tell.  Detached parameters make the nodes take their forward-only path (one set of
+    temporaries for all layers, cached bf16 weights, nothing saved)."""
+    return params if torch.is_grad_enabled() else tuple(p.detach() for p in params)
+
+
 _scratch: Dict[Tuple[str, int], torch.Tensor] = {}
 
 # bench.py hooks a probe here to bracket selected kernel launches with HIP events on the launch stream

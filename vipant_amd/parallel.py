@@ -108,24 +108,38 @@ class GradSync:
         self.buffers.append(flat)
 
     def reduce_params(self, params: Iterable[torch.nn.Parameter]):
-        """Bucket the (small) gradients that did not come through a layer bucket: patch embedding, read-out."""
-        grads = [p.grad for p in params if p.grad is not None]
-        if not active() or not grads:
+        """Bucket the (small) gradients that did not come through a layer bucket: patch embedding, read-out.  Started
+        asynchronously like the layer buckets; `wait()` hands the reduced slices back as the parameters' `.grad`."""
+        seen, plist = set(), []
+        for p in params:
+            if p.grad is not None and id(p) not in seen:
+                seen.add(id(p)); plist.append(p)
+        if not active() or not plist:
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self.reduce_async(flat)
-        self.wait()
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.reduce_async(flat, views, plist)
 
     def wait(self):
+        """Block until every bucket is reduced, then make the reduced slices the parameters' gradients.
+
+        A parameter can own several slices -- a siamese shared encoder runs the stack twice over the same weights, once per
+        tower, and each run hands over its own bucket -- so the slices of one parameter are summed; the first one is
+        installed as `.grad` by reference (no 352 MB copy-back per step), the rest are added to it."""
         for h in self.handles:
             h.wait()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        first = set()
         for p, v in self.pairs:
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                p.grad.copy_(v)
+            if p.grad is None:
+                continue
+            if id(p) not in first:
+                first.add(id(p))
+                p.grad = v
+            else:
+                p.grad.add_(v)
         self.handles, self.buffers, self.pairs = [], [], []

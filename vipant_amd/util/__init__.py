@@ -1,4 +1,4 @@
-"""Seeding / logging helpers with the reference's signatures (cvap/util/__init__.py:8-62)."""
+"""Seeding and logging for the trainer entry (the reference's helpers of the same names: cvap/util/__init__.py:8-37)."""
 import logging
 import os
 import random
@@ -7,59 +7,41 @@ import numpy
 import torch
 import torch.distributed as dist
 
+__all__ = ["seed_all_rng", "setup_logger"]
+
 
 def seed_all_rng(seed):
-    random.seed(seed)
-    numpy.random.seed(seed)
-    torch.manual_seed(seed)
+    """Python, NumPy and torch generators, same seed on every rank (train.py:40 of the reference)."""
+    for seeder in (random.seed, numpy.random.seed, torch.manual_seed):
+        seeder(seed)
 
 
 def setup_logger(output_dir=None, name="cvap", rank=0, output=None):
-    """Rank-0 console handler + one `train_{rank}.out` file per rank (cvap/util/__init__.py:13-37)."""
-    logger = logging.getLogger(name)
-    logger.setLevel(logging.INFO)
-    logger.propagate = False
-    logger.handlers.clear()
-    formatter = logging.Formatter("%(asctime)s - %(levelname)s - %(message)s")
+    """Logger `name`: console output on rank 0 only, plus `<output_dir>/train_<rank>.out` on every rank when `output` is
+    given.  Rank 0 creates the directory; the other ranks wait for it at a barrier."""
+    log = logging.getLogger(name)
+    log.setLevel(logging.INFO)
+    log.propagate = False
+    for old in list(log.handlers):
+        log.removeHandler(old)
+    fmt = logging.Formatter("%(asctime)s - %(levelname)s - %(message)s")
+
+    def attach(handler):
+        handler.setLevel(logging.INFO)
+        handler.setFormatter(fmt)
+        log.addHandler(handler)
+
     if rank == 0:
-        console = logging.StreamHandler()
-        console.setLevel(logging.INFO)
-        console.setFormatter(formatter)
-        logger.addHandler(console)
-    if output_dir is not None:
-        if os.path.exists(output_dir):
-            logger.info(f"Warning: the folder {output_dir} exists.")
-        elif rank == 0:
-            logger.info(f"Creating {output_dir}")
-            os.makedirs(output_dir, exist_ok=True)
-        if dist.is_available() and dist.is_initialized():
-            dist.barrier()
-        if output is not None:
-            handler = logging.FileHandler(os.path.join(output_dir, f"train_{rank}.out"), "w")
-            handler.setLevel(logging.INFO)
-            handler.setFormatter(formatter)
-            logger.addHandler(handler)
-    return logger
-
-
-def numel(model: torch.nn.Module, trainable: bool = False):
-    parameters = [p for p in model.parameters() if p.requires_grad or not trainable]
-    return sum(p.numel() for p in {p.data_ptr(): p for p in parameters}.values())
-
-
-def detect_nan(x):
-    return torch.isnan(x).any(), torch.isinf(x).any()
-
-
-class AverageMeter(object):
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.val = self.sum = self.count = self.avg = 0
-
-    def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+        attach(logging.StreamHandler())
+    if output_dir is None:
+        return log
+    if os.path.isdir(output_dir):
+        log.info(f"Warning: the folder {output_dir} exists.")
+    elif rank == 0:
+        log.info(f"Creating {output_dir}")
+        os.makedirs(output_dir, exist_ok=True)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if output is not None:
+        attach(logging.FileHandler(os.path.join(output_dir, f"train_{rank}.out"), mode="w"))
+    return log
