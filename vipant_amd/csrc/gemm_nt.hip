@@ -354,7 +354,8 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
     hipStream_t s = (hipStream_t)stream;
     const bool staged = (N % 8 == 0) && (ldc % 8 == 0) && !(dbg & 2);
     switch (epilogue) {
-        case VIPANT_EPI_BF16: return staged ? launch_persistent<VIPANT_EPI_BF16>(p, s) : launch<VIPANT_EPI_BF16>(p, s);
+        case VIPANT_EPI_BF16:
+            return staged ? launch_persistent<VIPANT_EPI_BF16>(p, s) : launch<VIPANT_EPI_BF16>(p, s);
         case VIPANT_EPI_F32: return launch<VIPANT_EPI_F32>(p, s);
         case VIPANT_EPI_RESIDUAL_F32:
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: residual epilogue needs aux");

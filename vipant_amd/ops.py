@@ -9,6 +9,7 @@ The residual stream and its gradient are fp32; every MFMA operand is bf16 (fp32 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -93,14 +94,16 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux
     return c
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False, a_colsum=None):
-    """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out); a_colsum (fp32 [P], optional) (+)= column sums of a."""
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False, a_colsum=None,
+            ws_name: str = "gemm_tn"):
+    """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out); a_colsum (fp32 [P], optional) (+)= column sums of a.
+    `ws_name`: the split-K workspace is shared by all calls of one name -- calls issued on different streams need their own."""
     _need(a, BF16, "gemm_tn.a"); _need(b, BF16, "gemm_tn.b"); _need(c, F32, "gemm_tn.c")
     M, P = a.shape
     Q = b.shape[1]
     assert b.shape[0] == M and tuple(c.shape) == (P, Q), (a.shape, b.shape, c.shape)
     nbytes = query("vipant_gemm_tn_workspace_bytes", M, P, Q)
-    ws = scratch("gemm_tn", nbytes, a.device)
+    ws = scratch(ws_name, nbytes, a.device)
     call("vipant_gemm_tn", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0), M, P, Q,
          int(accumulate), _ptr(a_colsum), ws.data_ptr(), ws.numel(), _stream())
     return c
@@ -282,6 +285,19 @@ class _LayerGrads:
             off += p
 
 
+# Measured on MI355X (profiles/r2_overlap_experiments.md): every contraction launch fills all 256 CUs with one 128-KiB-LDS
+# workgroup each, so a second queue only interleaves whole workgroups -- 124.23 vs 124.25 ms per step.  Off by default.
+_DW_OVERLAP = os.environ.get("VIPANT_DW_STREAM", "0") == "1"
+_dw_streams: Dict[int, torch.cuda.Stream] = {}
+
+
+def _dw_stream(device) -> torch.cuda.Stream:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _dw_streams:
+        _dw_streams[idx] = torch.cuda.Stream(device=device)
+    return _dw_streams[idx]
+
+
 class BackboneFn(torch.autograd.Function):
     """TransformerBackbone.forward = L x ResidualAttentionBlock (cvap/module/val.py:493-522) on the fp32
     residual stream x [batch*S, D].  One autograd node for the whole stack: the layer loop, the saved
@@ -355,6 +371,22 @@ class BackboneFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
         lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
         colsum(dx_b, lg.views[11])          # d c_proj.bias of the top block; lower blocks get theirs from ln_1's backward
+        # The four weight-gradient contractions of a block feed nothing in the dX chain: they run on a side stream, ordered
+        # behind their operands only, so their workgroups fill in beside the HBM-bound LayerNorm / attention kernels and the
+        # short last rounds of the dX contractions on the main stream (the reference's autograd runs all of it in series:
+        # cvap/monitor/cvalp.py:203).
+        main = torch.cuda.current_stream(dev)
+        side = _dw_stream(dev) if _DW_OVERLAP else None
+
+        def dweight(a, b, c, a_colsum=None):
+            if side is None:
+                gemm_tn(a, b, c, a_colsum=a_colsum)
+                return
+            side.wait_stream(main)                      # operands are complete on the main stream
+            with torch.cuda.stream(side):
+                gemm_tn(a, b, c, a_colsum=a_colsum, ws_name="gemm_tn_side")
+            a.record_stream(side); b.record_stream(side)        # not handed to another tensor while the side stream reads
+
         for l in reversed(range(L)):
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g = saved[13 * l:13 * l + 13]
             ln1w, _, _, _, _, _, ln2w, _, _, _, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
@@ -364,11 +396,11 @@ class BackboneFn(torch.autograd.Function):
             # c_proj + QuickGELU'
             du = torch.empty((M, 4 * D), dtype=BF16, device=dev)
             gemm_nt(dx_b, wpr_t, du, aux=u, epi=EPI_DQUICKGELU)
-            gemm_tn(dx_b, g, d_wpr)
+            dweight(dx_b, g, d_wpr)
             # c_fc
             dh2 = torch.empty((M, D), dtype=BF16, device=dev)
             gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
-            gemm_tn(du, h2, d_wfc, a_colsum=d_bfc)
+            dweight(du, h2, d_wfc, a_colsum=d_bfc)
             del du
             # ln_2 (+ residual gradient); its output dx1 is also d(out_proj output): column sum = d out_proj.bias
             dx1 = torch.empty((M, D), dtype=F32, device=dev)
@@ -378,24 +410,28 @@ class BackboneFn(torch.autograd.Function):
             # out_proj
             do = dh2
             gemm_nt(dx1_b, wo_t, do, epi=EPI_BF16)
-            gemm_tn(dx1_b, o, d_wo)
+            dweight(dx1_b, o, d_wo)
             # attention core
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
             # in_proj
             dh1 = do
             gemm_nt(dqkv, wqkv_t, dh1, epi=EPI_BF16)
-            gemm_tn(dqkv, h1, d_wqkv, a_colsum=d_bqkv)
+            dweight(dqkv, h1, d_wqkv, a_colsum=d_bqkv)
             del dqkv
-            # ln_1 (+ residual gradient), in place on the stream buffers; the produced dx is d(c_proj output) of the
-            # block below: its column sum is that block's d c_proj.bias
-            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln1w, dbeta=d_ln1b,
+            # ln_1 (+ residual gradient): the fp32 stream gradient is updated in place; its bf16 copy goes to a fresh buffer
+            # when the side stream may still be reading the old one (d out_proj.weight above).  The produced dx is
+            # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
+            dxn_b = dx1_b if side is None else torch.empty((M, D), dtype=BF16, device=dev)
+            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dxn_b, dgamma=d_ln1w, dbeta=d_ln1b,
                           dx_colsum=lg_below.views[11] if lg_below is not None else None)
-            dx, dx_b = dx1, dx1_b
+            dx, dx_b = dx1, dxn_b
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
             if ctx.grad_sync is not None:
-                ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
+                ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12], also_after=side)
             lg = lg_below
+        if side is not None:
+            main.wait_stream(side)          # every weight gradient is complete before autograd hands them on
         ctx.wts = None
         need = ctx.needs_input_grad
         out_grads = [gr if need[5 + i] else None for i, gr in enumerate(grads)]
