@@ -305,6 +305,298 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong persistent kernel (bf16-output epilogues, K >= 128).
+//
+// In the kernel above both waves of a SIMD do the same thing at the same time: at the top of every K-tile all eight
+// waves issue their LDS-DMA burst (8 x ~150 cycles of issue each) and no MFMA runs; measured, the loop without its DMA
+// is 25-30 % faster.  Here the two wave groups of a workgroup (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; wave w and
+// w+4 share a SIMD) run the SAME instruction stream HALF A K-TILE APART, separated by the workgroup barrier: while one
+// group issues its DMA and starts the first 32-deep half of its K-tile, the other is in the MFMA-only second half, so
+// every SIMD always has a wave that can feed the matrix pipe.
+//
+// What makes the lag legal with 160 KiB of LDS:
+//   * A rows are private to a group (only waves with wm = g read rows g*128..+127): two 16 KiB stages per group, filled
+//     by the group itself one K-tile ahead;
+//   * B is read by both groups, so the slot of K-tile k is still being read by the lagging group when the leading one
+//     wants K-tile k+1 filled: B lives in a ring of THREE 32 KiB slots.  Group 0 fills rows 0-127 of slot (k+1) at the
+//     start of its K-tile k; group 1 fills rows 128-255 of slot (k+2) at the start of ITS K-tile k (half a K-tile later),
+//     which gives every fill at least one full K-tile to land before its first reader and never touches a slot that any
+//     wave can still be reading;
+//   * the K-tile stream runs on across tile boundaries (next tile's descriptors, K offset 0), the epilogue sits between
+//     two tiles' K-loops and stages through the one A stage of the group that the stream does not need (4 rounds of
+//     32 rows), so both groups execute the same number of barriers per tile and stay exactly one barrier apart;
+//   * every wave issues the same number of DMA instructions per K-tile whatever happens (past the last tile they go
+//     through a zero-length descriptor: no traffic), so the counted vmcnt waits are always exact.
+// Barrier intervals per wave and K-tile k: [DMA issue, 32 MFMAs (k-step 0)] | [32 MFMAs (k-step 1)].
+// Waits before the barrier that ends an interval -- group 0: none | vmcnt(0);  group 1: vmcnt(8) | vmcnt(4).
+constexpr int PP_A_STAGE = 128 * BK * 2;                 // 16 KiB
+constexpr int PP_B_BASE = 4 * PP_A_STAGE;                // 64 KiB: [group][stage]
+constexpr int PP_B_SLOT = BN * BK * 2;                   // 32 KiB
+constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
+
+template <int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wl = wave & 3;            // grp = wm, wl = wn
+    const int frow = lane & 15, fq = lane >> 4, fs = (lane >> 1) & 7;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int ntiles = ntm * ntn;
+    const int G = gridDim.x;                                   // multiple of 8, <= ntiles rounded up
+    const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
+    const int nk = p.K / BK;
+
+    // DMA: wave fills row blocks wave*4 .. wave*4+3 (8 rows x 128 B) of the tile's A and B rows, as in the kernel above
+    uint32_t voffA[2], voffB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        voffA[i] = (uint32_t)(r * p.lda * 2 + c * 16);
+        voffB[i] = (uint32_t)(r * p.ldb * 2 + c * 16);
+    }
+    const uint32_t waveA = (uint32_t)(wave * 32 * p.lda * 2), waveB = (uint32_t)(wave * 32 * p.ldb * 2);
+    const uint32_t pairA = (uint32_t)(16 * p.lda * 2), pairB = (uint32_t)(16 * p.ldb * 2);
+    char* const ldsA = smem + grp * (2 * PP_A_STAGE) + wl * 4096;          // + stage * PP_A_STAGE
+    char* const ldsB = smem + PP_B_BASE + wave * 4096;                      // + slot * PP_B_SLOT
+    // fragment reads
+    uint32_t offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t cb = (uint32_t)(((ks * 4 + fq) ^ fs) << 4);
+        offA[ks] = (uint32_t)(grp * (2 * PP_A_STAGE) + frow * 128) + cb;
+        offB[ks] = (uint32_t)(PP_B_BASE + (wl * 64 + frow) * 128) + cb;
+    }
+
+    struct TileDesc { __amdgpu_buffer_rsrc_t a, b; int m0, n0; };
+    auto describe = [&](int tile) {
+        TileDesc d;
+        if (tile < ntiles) {
+            const int tm = tile / ntn, tn = tile % ntn;
+            d.m0 = tm * BM; d.n0 = tn * BN;
+            const int64_t a_bytes = ((int64_t)(p.M - d.m0) * p.lda - (p.lda - p.K)) * 2;
+            const int64_t b_bytes = ((int64_t)(p.N - d.n0) * p.ldb - (p.ldb - p.K)) * 2;
+            d.a = make_rsrc(p.A + (int64_t)d.m0 * p.lda, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
+            d.b = make_rsrc(p.B + (int64_t)d.n0 * p.ldb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
+        } else {                                   // past the last tile: zero records, every lane out of range, no traffic
+            d.m0 = p.M; d.n0 = 0;
+            d.a = make_rsrc(p.A, 0); d.b = make_rsrc(p.B, 0);
+        }
+        return d;
+    };
+    auto fill_a = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, uint32_t koff) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            lds_dma16(rs, ldsA + stage * PP_A_STAGE + i * 1024, voffA[i & 1], koff + waveA + (i >> 1) * pairA);
+    };
+    auto fill_b = [&](const __amdgpu_buffer_rsrc_t& rs, int slot, uint32_t koff) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            lds_dma16(rs, ldsB + slot * PP_B_SLOT + i * 1024, voffB[i & 1], koff + waveB + (i >> 1) * pairB);
+    };
+
+    f32x4 acc[8][4];
+    // Fragment pipeline of one 32-deep k-step (= one barrier interval): B fragments up front, A fragments two MFMA groups
+    // ahead in a 3-deep ring.  (Reading k-step 1's first fragments ahead of the mid-K-tile barrier measured 5 % slower.)
+    bf16x8 fb[4], fa[3];
+    auto frag_head = [&](int ks, int stage, int slot) {
+        const char* sa = smem + stage * PP_A_STAGE + offA[ks];
+        const char* sb = smem + slot * PP_B_SLOT + offB[ks];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb + j * 2048);
+        fa[0] = *(const bf16x8*)(sa);
+        fa[1] = *(const bf16x8*)(sa + 2048);
+    };
+    // 32 MFMAs of k-step ks; `dma(i)` is called after MFMA group i (used to spread the K-tile's DMA issue over the groups)
+    auto half_body = [&](int ks, int stage, auto&& dma) {
+        const char* sa = smem + stage * PP_A_STAGE + offA[ks];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i + 2 < 8) fa[(i + 2) % 3] = *(const bf16x8*)(sa + (i + 2) * 2048);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i % 3], acc[i][j], 0, 0, 0);
+            dma(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    int tile = lane_pos;
+    TileDesc cur = describe(tile), nxt = describe(tile + G);
+    int gk = 0, slot = 0;                       // K-tile counter of the stream: A stage = gk & 1, B slot = gk % 3
+    // prologue: K-tile 0 of the first tile (and, for group 1, its B rows of K-tile 1)
+    fill_a(cur.a, 0, 0);
+    fill_b(cur.b, 0, 0);
+    if (grp == 1) {
+        const bool wrap = nk < 2;
+        fill_b(wrap ? nxt.b : cur.b, 1, wrap ? 0u : (uint32_t)(BK * 2));
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // the lag: group 1 runs one barrier interval behind group 0
+
+    while (tile < ntiles) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 bv[4];
+        for (int k = 0; k < nk; ++k) {
+            const int stage = gk & 1;
+            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+            if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
+                load_bias<EPI>(p, cur.n0, wl, fq, bv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
+            }
+            {   // first interval: DMA of the stream's next K-tile(s), k-step 0
+                const bool w1 = k + 1 >= nk, w2 = k + 2 >= nk;
+                const __amdgpu_buffer_rsrc_t& ra = w1 ? nxt.a : cur.a;
+                const __amdgpu_buffer_rsrc_t& rb = grp == 0 ? (w1 ? nxt.b : cur.b) : (w2 ? nxt.b : cur.b);
+                const uint32_t ka = w1 ? 0u : (uint32_t)((k + 1) * BK * 2);
+                const uint32_t kb = grp == 0 ? ka : (uint32_t)((w2 ? k + 2 - nk : k + 2) * BK * 2);
+                char* const da = ldsA + (stage ^ 1) * PP_A_STAGE;
+                char* const db = ldsB + (grp == 0 ? slot1 : slot2) * PP_B_SLOT;
+                auto dma_piece = [&](int i) {      // piece i of this wave's 8: 4 of A, then 4 of B
+                    if (i < 4) lds_dma16(ra, da + i * 1024, voffA[i & 1], ka + waveA + (i >> 1) * pairA);
+                    else lds_dma16(rb, db + (i - 4) * 1024, voffB[i & 1], kb + waveB + ((i - 4) >> 1) * pairB);
+                };
+                if (VAR == 1) {                    // fragment reads first: their LDS round trip runs under the DMA issue
+                    frag_head(0, stage, slot);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dma_piece(i);
+                } else {                           // burst at the top of the K-tile
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dma_piece(i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    frag_head(0, stage, slot);
+                }
+                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                half_body(0, stage, [](int) {});
+                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                sync();
+            }
+            {   // second interval: k-step 1
+                frag_head(1, stage, slot);
+                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                half_body(1, stage, [](int) {});
+                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sync();
+            }
+            ++gk;
+            slot = slot1;
+        }
+        // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
+        char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
+        const int tl = tid & 255;
+        bf16x8 un[4];                                // DQUICKGELU: pre-activations of the next round, loaded one round ahead
+        auto load_aux = [&](int r) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = t * 256 + tl;
+                const int R = idx >> 5, ch = idx & 31;
+                const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + ch * 8;
+                un[t] = (m < p.M && n < p.N) ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
+            }
+        };
+        if (EPI == VIPANT_EPI_DQUICKGELU) load_aux(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = r * 2 + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int colbyte = wl * 128 + j * 32 + fq * 8;
+                    *(bf16x4*)(stg + (ii * 16 + frow) * 512 + (((colbyte >> 4) ^ frow) << 4) + (colbyte & 8)) =
+                        f32x4_to_bf16x4(acc[i][j] + bv[j]);
+                }
+            }
+            sync();
+            bf16x8 u8[4];
+            if (EPI == VIPANT_EPI_DQUICKGELU) {      // this round's pre-activations arrived during the previous round
+#pragma unroll
+                for (int t = 0; t < 4; ++t) u8[t] = un[t];
+                if (r + 1 < 4) load_aux(r + 1);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = t * 256 + tl;
+                const int R = idx >> 5, ch = idx & 31;
+                const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + ch * 8;
+                if (m < p.M && n < p.N && !(p.dbg & 1)) {
+                    const bf16x8 v = *(const bf16x8*)(stg + R * 512 + ((ch ^ (R & 15)) << 4));
+                    const int64_t o = (int64_t)m * p.ldc + n;
+                    if (EPI == VIPANT_EPI_BF16) {
+                        *(bf16x8*)((bf16_t*)p.C + o) = v;
+                    } else if (EPI == VIPANT_EPI_QUICKGELU) {
+                        *(bf16x8*)((bf16_t*)p.aux + o) = v;
+                        bf16x8 g;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float u = (float)v[e];
+                            g[e] = (bf16_t)(u * fast_sigmoid(1.702f * u));
+                        }
+                        *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    } else {  // VIPANT_EPI_DQUICKGELU
+                        bf16x8 d;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float u = (float)u8[t][e];
+                            const float sg = fast_sigmoid(1.702f * u);
+                            d[e] = (bf16_t)((float)v[e] * (sg * (1.0f + 1.702f * u * (1.0f - sg))));
+                        }
+                        *(bf16x8*)((bf16_t*)p.C + o) = d;
+                    }
+                }
+            }
+            sync();
+        }
+        tile += G;
+        cur = nxt;
+        nxt = describe(tile + G);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
+}
+
+template <int EPI, int VAR>
+int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        configured = true;
+    }
+    const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+template <int EPI>
+int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
+    if (p.dbg & 32) return launch_pp_variant<EPI, 1>(p, stream);
+    if (p.dbg & 64) return launch_pp_variant<EPI, 2>(p, stream);
+    return launch_pp_variant<EPI, 0>(p, stream);
+}
+
 template <int EPI>
 int32_t launch_persistent(const GemmNT& p, hipStream_t stream) {
     static bool configured = false;
@@ -353,8 +645,10 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
     GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg};
     hipStream_t s = (hipStream_t)stream;
     const bool staged = (N % 8 == 0) && (ldc % 8 == 0) && !(dbg & 2);
+    const bool pp = staged && K >= 128 && !(dbg & 16);
     switch (epilogue) {
         case VIPANT_EPI_BF16:
+            if (pp) return launch_pp<VIPANT_EPI_BF16>(p, s);
             return staged ? launch_persistent<VIPANT_EPI_BF16>(p, s) : launch<VIPANT_EPI_BF16>(p, s);
         case VIPANT_EPI_F32: return launch<VIPANT_EPI_F32>(p, s);
         case VIPANT_EPI_RESIDUAL_F32:
@@ -362,9 +656,11 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
             return staged ? launch_persistent<VIPANT_EPI_RESIDUAL_F32>(p, s) : launch<VIPANT_EPI_RESIDUAL_F32>(p, s);
         case VIPANT_EPI_QUICKGELU:
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: quickgelu epilogue needs aux (U out)");
+            if (pp) return launch_pp<VIPANT_EPI_QUICKGELU>(p, s);
             return staged ? launch_persistent<VIPANT_EPI_QUICKGELU>(p, s) : launch<VIPANT_EPI_QUICKGELU>(p, s);
         case VIPANT_EPI_DQUICKGELU:
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: dquickgelu epilogue needs aux (U in)");
+            if (pp) return launch_pp<VIPANT_EPI_DQUICKGELU>(p, s);
             return staged ? launch_persistent<VIPANT_EPI_DQUICKGELU>(p, s) : launch<VIPANT_EPI_DQUICKGELU>(p, s);
         case VIPANT_EPI_SCALE_F32: return launch<VIPANT_EPI_SCALE_F32>(p, s);
         default:
