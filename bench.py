@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 D, L, E, HEADS = 768, 12, 512, 12
+DOMINANT_KERNEL = "gemm_nt_pp_kernel<3, 0>"       # c_fc forward + QuickGELU (name as rocprofv3 prints it)
 
 
 def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
@@ -31,12 +32,17 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
     return layers * S * (24 * width * width + 4 * S * width) + 2 * P * kpatch * width + 2 * width * embed
 
 
+PMC_FILE = "profiles/r2_pmc_traffic.json"
+
+
 def pmc_traffic(M, N, K):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json:
-    FETCH_SIZE x 2 + WRITE_SIZE, see that file for the commands and the calibration); None for any other shape."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (PMC_FILE: FETCH_SIZE x 2 +
+    WRITE_SIZE, separate --pmc passes; that file holds the commands, the build it was taken on and the kernel name).  The
+    counters cannot be collected inside this process, so the bench line names the file the number came from (`traffic_source`)
+    and reports None when the file has no entry for the kernel / shape that is being timed."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(f"gemm_nt_persistent_kernel<3> M={M} N={N} K={K}")
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            k = json.load(f)["kernels"].get(f"{DOMINANT_KERNEL} M={M} N={N} K={K}")
         return None if k is None else k["fetch_bytes"] + k["write_bytes"]
     except (OSError, KeyError, ValueError):
         return None
@@ -59,14 +65,37 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu():
+    """(model name, physical cores) of this box from lscpu; falls back to os.cpu_count()."""
+    import subprocess
+    model, cores_per_socket, sockets = "unknown", None, None
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "Model name":
+                model = val
+            elif key == "Core(s) per socket":
+                cores_per_socket = int(val)
+            elif key == "Socket(s)":
+                sockets = int(val)
+    except Exception:
+        pass
+    physical = cores_per_socket * sockets if cores_per_socket and sockets else (os.cpu_count() or 1)
+    return model, physical
+
+
 def cpu_baseline(args, T, Fq):
-    """The CPU oracle (oracle/ref_cpu.py, pinned against the reference by tests/golden) timed on this box's host
-    cores on a bounded sample of the same workload: same shapes, `--cpu-batch` pairs, fp32, 1 warm-up + 1 timed step
-    (image tower forward + audio tower forward/backward + InfoNCE)."""
+    """The CPU oracle (oracle/ref_cpu.py, pinned against the reference by tests/golden) timed on this box's host cores,
+    SURVEY.md 8-D5 protocol, `torch.set_num_threads(physical cores)`:
+      * cfg1 exactly (BASELINE.json configs[0]): batch 32, 256 x 64 spectrograms, precomputed image embeddings, fp32,
+        forward + backward + LARS, 2 warm-up + 5 timed steps, median;
+      * the headline workload's shapes (configs[1]) on a bounded sample: `--cpu-batch` pairs, image tower forward + audio
+        tower forward / backward + InfoNCE + LARS, 1 warm-up (2 pairs) + 1 timed step -- `value` is this leg's pairs/s."""
     from oracle import ref_cpu as R
+    model, physical = host_cpu()
+    torch.set_num_threads(physical)
     torch.manual_seed(0)
-    b = args.cpu_batch
-    stride, S, pr = R.vit_position_resolution([T, Fq], 32, [16, 24])
 
     def rand_sd(shapes, grad):
         sd = {}
@@ -79,26 +108,63 @@ def cpu_baseline(args, T, Fq):
                 t = torch.randn(shp) * (shp[-1] ** -0.5 if len(shp) > 1 else 0.02)
             sd[k] = t.requires_grad_(grad)
         return sd
+
+    def lars_all(params, mus, lw, lb):
+        with torch.no_grad():
+            for k, v in params.items():
+                if v.grad is None:
+                    continue
+                p_new, mus[k] = R.lars_step(v.detach(), v.grad, mus[k], lw if v.ndim > 1 else lb)
+                v.copy_(p_new)
+                v.grad = None
+
+    # ---- leg 1: cfg1 exactly
+    b1, T1, F1 = 32, 256, 64
+    stride1, S1, pr1 = R.vit_position_resolution([T1, F1], 32, [16, 24])
+    sd1 = rand_sd(R.audio_head_shapes(D, L, E, S1), True)
+    ls1 = torch.tensor(2.6593, requires_grad=True)
+    p1 = dict(sd1, logit_scale=ls1)
+    mu1 = {k: torch.zeros_like(v) for k, v in p1.items()}
+    aud1, img1 = torch.randn(b1, 1, T1, F1), torch.randn(b1, E)
+    times = []
+    for it in range(7):
+        t0 = time.perf_counter()
+        lw, lb = R.adjust_learning_rate(it + 10, epochs=1000, steps_per_epoch=10, warmup_epoch=10, batch_size=b1,
+                                        lr_weight=0.2, lr_bias=0.0048)
+        fa = R.vit_head_forward(aud1, sd1, width=D, layers=L, stride=stride1, position_resolution=pr1)
+        loss = R.ce_loss_head(R.l2_normalize(img1), fa, ls1)
+        loss.backward()
+        lars_all(p1, mu1, lw, lb)
+        times.append(time.perf_counter() - t0)
+    t_cfg1 = sorted(times[2:])[2]
+
+    # ---- leg 2: bounded sample at the headline shapes
+    b = args.cpu_batch
+    stride, S, pr = R.vit_position_resolution([T, Fq], 32, [16, 24])
     asd = rand_sd(R.audio_head_shapes(D, args.layers, E, S), True)
     isd = rand_sd(R.audio_head_shapes(D, args.layers, E, 50), False)
     ls = torch.tensor(2.6593, requires_grad=True)
+    p2 = dict(asd, logit_scale=ls)
+    mu2 = {k: torch.zeros_like(v) for k, v in p2.items()}
 
     def step(n):
         aud, img = torch.randn(n, 1, T, Fq), torch.randn(n, 3, 224, 224)
         with torch.no_grad():
             fi = R.vit_head_forward(img, isd, width=D, layers=args.layers, stride=[32, 32], position_resolution=(7, 7))
         fa = R.vit_head_forward(aud, asd, width=D, layers=args.layers, stride=stride, position_resolution=pr)
-        loss = R.ce_loss_head(fi, fa, ls)
-        loss.backward()
-        for v in asd.values():
-            v.grad = None
+        R.ce_loss_head(fi, fa, ls).backward()
+        lars_all(p2, mu2, 0.4, 0.0096)
     step(2)
     t0 = time.perf_counter()
     step(b)
     dt = time.perf_counter() - t0
-    return {"value": round(b / dt, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 timed step of {b} pairs at the same shapes ({T}x{Fq} spectrograms, 3x224x224 images, "
-                      f"{args.layers} layers), fp32 oracle, after a 2-pair warm-up; {dt:.1f} s"}
+    return {"value": round(b / dt, 3), "unit": "pairs/s", "cores": physical, "kind": "port", "cpu_model": model,
+            "threads": torch.get_num_threads(),
+            "sample": f"1 timed step of {b} pairs at the headline shapes ({T}x{Fq} spectrograms, 3x224x224 images, {args.layers} "
+                      f"layers), fp32 oracle incl. LARS, after a 2-pair warm-up; {dt:.1f} s",
+            "cfg1": {"workload": "BASELINE.json configs[0]: batch 32, 256x64 spectrograms, precomputed image embeddings, fp32, "
+                                 "fwd + bwd + LARS; 2 warm-up + 5 timed steps, median",
+                     "median_step_s": round(t_cfg1, 3), "pairs_per_s": round(b1 / t_cfg1, 2)}}
 
 
 def bench_at(args, world, rank, local_rank, dev, use_dist):
@@ -245,9 +311,9 @@ def main():
         "loss": round(float(loss.detach()), 4),
         "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_persistent_kernel<3> (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (Mrows, 4 * D, D),
+        "roofline": {"bound": "mfma", "kernel": "%s (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (DOMINANT_KERNEL, Mrows, 4 * D, D),
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * D, D),
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * D, D), "traffic_source": PMC_FILE,
                      "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * D + 4 * D * D + 2 * Mrows * 4 * D),
                      "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
     }

@@ -21,6 +21,16 @@ import gen  # noqa: E402
 DEV = "cuda:0"
 
 
+def observe(name, **vals):
+    """Observed parity numbers go to gpurun_out/parity_observed.jsonl (summarised in profiles/r2_parity_observed.md)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_observed.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **{k: float(v) for k, v in vals.items()}}) + "\n")
+
+
 @pytest.fixture(scope="module")
 def M():
     import vipant_amd.module as mod
@@ -182,6 +192,11 @@ def test_image_head_golden(M, golden):
     assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
 
 
+# |loss - reference| budgets, about 2x the values observed on MI355X (profiles/r2_parity_observed.md); the north-star budget
+# of 1e-3 is for the loss kernel's own boundary (tests/test_kernels_gpu.py::test_infonce_golden, observed < 5e-5 x loss)
+E2E_LOSS_BUDGET = {"L2": 4e-3, "L12": 1e-3, "T1000": 3.5e-3}      # observed 2.1e-3 (b=8), 2.4e-4 (b=32), 1.7e-3 (b=4)
+
+
 @pytest.mark.parametrize("tag,L,b,T,Fq", [("L2", 2, 8, 256, 64), ("L12", 12, 32, 256, 64), ("T1000", 2, 4, 1000, 128)])
 def test_end_to_end_golden(M, golden, tag, L, b, T, Fq):
     """VA step on precomputed image embeddings at the cfg1 shape (256x64 spectrograms) and at the shipped default spectrogram
@@ -205,7 +220,10 @@ def test_end_to_end_golden(M, golden, tag, L, b, T, Fq):
     assert float(cos.min()) > 0.9995, float(cos.min())
     # loss: north-star budget 1e-3 is for the K8 boundary (tests/test_kernels_gpu.py); end to end through bf16
     # towers the stated budget is 5e-3 absolute on a loss of ~2 ln(b)
-    assert abs(float(loss) - float(g["loss"])) < 5e-3, (float(loss), float(g["loss"]))
+    observe(f"e2e_{tag}", loss_hip=float(loss), loss_ref=float(g["loss"]), loss_abs_err=abs(float(loss) - float(g["loss"])),
+            feat_rel_err=rel_err(feat, g["feat"]), min_cos=float(cos.min()),
+            dls_rel_err=abs(float(lhead.logit_scale.grad) - float(g["dls"])) / max(abs(float(g["dls"])), 1e-3))
+    assert abs(float(loss) - float(g["loss"])) < E2E_LOSS_BUDGET[tag], (float(loss), float(g["loss"]))
     assert abs(float(lhead.logit_scale.grad) - float(g["dls"])) < 2e-2 * max(abs(float(g["dls"])), 1e-3)
     grads = {k: p.grad for k, p in head.named_parameters()}
     keys = list(g["keys"])
@@ -325,3 +343,30 @@ def test_train_entry_runs_both_launch_scripts(tmp_path, monkeypatch):
     ck = torch.load(tmp_path / "t" / "00000002.pth", weights_only=False)
     assert len(ck["model"]) == 4 and "encoder.resblocks.0.attn.in_proj_weight" in ck["model"][1]
     assert "loss_head_al.logit_scale" in ck["model"][3] and ck["cfg"]["worker"] == "CVALP"
+
+
+def test_torch_optim_branch_adam_with_warmup():
+    """`optimizer.use_lars=False` (cvap/monitor/cvalp.py:338-342, 185-209): torch.optim.Adam + MultiStepLR from the config,
+    linear warm-up over `warmup_steps`, per-batch scheduler stepping after warm-up; forward / backward still the HIP path."""
+    from vipant_amd.config import compose
+    from vipant_amd.monitor import VAMonitor
+    ov = ("+running=bimodal worker=CVALP mode=dp eval=False num_gpus=1 +model/image=vit_val +model/audio=vit_val "
+          "+model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=1 running.audio.max_len=256 "
+          "running.audio.num_mel_bins=64 running.batch_size=8 running.epochs=1 running.frame_emb=synthetic "
+          "running.synthetic_steps=3 running.save_epoch=False optimizer.use_lars=False optimizer.warmup_steps=2 "
+          "optimizer.batch_sch=True optimizer.steps=[1] optimizer.lr=1e-3").split()
+    cfg = compose(ov)
+    cfg.rank = 0
+    torch.manual_seed(cfg.seed)
+    logs = []
+    mon = VAMonitor(cfg, logs.append, torch.device(DEV))
+    assert isinstance(mon.optimizer, torch.optim.Adam) and isinstance(mon.scheduler, torch.optim.lr_scheduler.MultiStepLR)
+    before = {k: v.detach().clone() for k, v in mon.model.named_parameters() if v.requires_grad}
+    mon.learn()
+    assert mon.total_step == 3 and math.isfinite(float(mon.total_loss))
+    warm = [m for m in logs if m.startswith("warmup lr")]
+    assert len(warm) == 2 and "5.00e-04" in warm[0] and "1.00e-03" in warm[1], warm       # ratio 1/2, 2/2 of lr = 1e-3
+    assert abs(mon.optimizer.param_groups[0]["lr"] - 1e-3 * 0.5) < 1e-12                    # one scheduler step past milestone 1
+    moved = sum(int(not torch.equal(v.detach(), before[k])) for k, v in mon.model.named_parameters() if k in before)
+    assert moved == len(before)

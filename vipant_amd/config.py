@@ -54,9 +54,15 @@ def _parse_value(text: str) -> Any:
     if text == "":
         return ""
     try:
-        return yaml.safe_load(text)
+        val = yaml.safe_load(text)
     except yaml.YAMLError:
         return text
+    if isinstance(val, str):        # YAML 1.1 reads `1e-3` / `1e9` as strings; Hydra's grammar reads them as floats
+        try:
+            return float(val)
+        except ValueError:
+            return val
+    return val
 
 
 def _set_path(cfg: dict, path: str, value: Any, create: bool):

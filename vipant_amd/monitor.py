@@ -156,12 +156,23 @@ class Monitor(object):
         self.timeit(all_time)
         nchunk = parallel.world_size()
         ocfg = self.cfg.optimizer
+        warmup_step_rate = max(int(ocfg.warmup_steps) // 20, 1)      # cvalp.py:177
         for step, batch in enumerate(self.dataloader, start=iepoch * len(self.dataloader)):
             images, audios, text, _, _ = self.make_batch(batch)
             self.timeit(all_time, key="data")
             if ocfg.use_lars:
                 adjust_learning_rate(ocfg, self.optimizer, self.dataloader, step)
+            # linear warm-up of a torch.optim optimizer (cvalp.py:185-198); always applied at the very first step
+            warmup = (not ocfg.use_lars) and ocfg.warmup and (self.total_step + 1) <= ocfg.warmup_steps
+            if warmup and ((self.total_step + 1) % warmup_step_rate == 0 or self.total_step == 0):
+                ratio = (self.total_step + 1) / ocfg.warmup_steps
+                for param_group in self.optimizer.param_groups:
+                    param_group["lr"] = ratio * param_group["initial_lr"]
+                lrs = " ".join(f"{g['lr']:.2e}" for g in self.optimizer.param_groups)
+                self.echo(f"warmup lr: {lrs} @ {self.total_step}")
             loss = self.step(images, audios, text)
+            if not ocfg.use_lars and ocfg.batch_sch and not warmup:
+                self.scheduler.step()               # after all warm-up is completed (cvalp.py:207-209)
             self.timeit(all_time, key="model")
             self.total_step += 1
             self.total_loss += loss.detach()
@@ -190,6 +201,8 @@ class Monitor(object):
                 if self.cfg.rank <= 0:
                     self.save()
             self.timeit(all_time, key="report")
+        if not ocfg.use_lars and not ocfg.batch_sch:
+            self.scheduler.step()                   # per-epoch schedule (cvalp.py:270-271)
         self.timeit(all_time, show=True)
 
     # ------------------------------------------------------------------ cvalp.py:274-300
@@ -239,8 +252,12 @@ class Monitor(object):
             self.optimizer = LARS(param_groups, lr=0., weight_decay=ocfg.weight_decay,
                                   weight_decay_filter=exclude_bias_or_norm, lars_adaptation_filter=exclude_bias_or_norm)
         else:
-            raise NotImplementedError("only the LARS branch (optimizer.use_lars=True, the default of both launch scripts) "
-                                      "is on the accelerated path")
+            # cvalp.py:338-342: any torch.optim optimizer + lr scheduler named in the config (`optimizer.optimizer`,
+            # `optimizer.scheduler`).  The update itself runs through torch's own optimizer kernels -- only LARS, the default
+            # of both launch scripts, has a fused HIP step; forward / backward are the HIP path either way.
+            ocfg_opt, ocfg_sch = ocfg.optimizer, ocfg.scheduler
+            self.optimizer = getattr(torch.optim, ocfg_opt[0])(param_groups, **dict(ocfg_opt[1]))
+            self.scheduler = getattr(torch.optim.lr_scheduler, ocfg_sch[0])(self.optimizer, **dict(ocfg_sch[1]))
         if self.cfg.verbose:
             self.echo("Gradienting The Following Parameters:")
             for k, v in self.model.named_parameters():
