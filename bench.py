@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--mels", type=int, default=128)
     ap.add_argument("--layers", type=int, default=L)
+    ap.add_argument("--width", type=int, default=D, help="audio tower width (heads = width // 64, cvap/module/val.py:474); "
+                    "1024 with --layers 24 is the audio ViT-L of BASELINE configs[4]")
+    ap.add_argument("--recompute-mlp", action="store_true", help="running.recompute_mlp: MLP activations re-made in the backward")
+    ap.add_argument("--micro-batch", type=int, default=0, help="running.micro_batch: towers in micro-batches under one loss")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
@@ -178,7 +182,9 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
     ov = ("+running=trimodal monitor=VALMonitor worker=CVALP mode=ddp eval=False +model/image=vit_val +model/audio=vit_val "
           "+model/text=transformer_val +model/loss=ce_val +optimizer=standard +running/audio=default "
           "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True "
-          f"running.imagine=False model.loss.va=False model.image.encoder.layers={args.layers} +running.negatives=local "
+          f"running.imagine=False model.loss.va=False model.image.encoder.layers={min(args.layers, 12)} "
+          f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} +running.negatives=local "
+          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} "
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
           f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -213,17 +219,21 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
         dt = float(tmax)
     ms = dt / args.steps * 1e3
     S = mon.model.audio_head.misc.positional_embedding.shape[0]
-    step_flops = b * (3 * tower_fwd_flops(S, 1024, S - 1, layers=args.layers)
+    # algorithmic work of the step (recomputation and the micro-batch pre-pass are NOT counted as work done)
+    algo_flops = b * (3 * tower_fwd_flops(S, 1024, S - 1, width=args.width, layers=args.layers)
                       + 12 * 77 * (24 * 512 * 512 + 4 * 77 * 512) + 2 * 512 * E) + 6.0 * b * b * E
     out = {"metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"AT fine-tuning step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-B/"
-                                  f"{args.layers}L fwd+bwd + frozen CLIP text tower (L=77) fwd + InfoNCE(al) + LARS, local negatives "
-                                  "(BASELINE.json configs[2]); NOT the headline configuration",
-                      "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local"},
-           "loss": round(float(loss.detach()), 4), "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
-           "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+           "config": {"workload": f"AT fine-tuning step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT width "
+                                  f"{args.width} / {args.layers}L fwd+bwd + frozen CLIP text tower (L=77) fwd + InfoNCE(al) + LARS, local "
+                                  "negatives (BASELINE.json configs[2]; configs[4]'s tower with --width 1024 --layers 24, bf16 weights); "
+                                  "NOT the headline configuration",
+                      "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local",
+                      "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch)},
+           "loss": round(float(loss.detach()), 4), "step_tflops": round(algo_flops / (ms * 1e-3) / 1e12, 1),
+           "step_mfma_frac": round(algo_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -252,7 +262,9 @@ def main():
         return bench_at(args, world, rank, local_rank, dev, use_dist)
     ov = ("+running=bimodal worker=CVALP mode=ddp eval=False +model/image=vit_val +model/audio=vit_val +model/text=dummy "
           "+model/loss=ce +optimizer=standard +running/audio=default model.audio.pre_encoder.in_channels=3 "
-          f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={args.layers} "
+          f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={min(args.layers, 12)} "
+          f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} "
+          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} "
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} "
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -277,6 +289,7 @@ def main():
     # live per-launch timing of the dominant kernel: c_fc forward contraction (EPI_QUICKGELU), M = b*S, N = 4D, K = D
     S = mon.model.audio_head.misc.positional_embedding.shape[0]
     Mrows = b * S
+    W = args.width
     ops.KERNEL_PROBE["gemm_nt"] = {"events": [], "match": lambda epi, M, N, K: epi == ops.EPI_QUICKGELU and M == Mrows}
     if use_dist:
         dist.barrier()
@@ -295,26 +308,26 @@ def main():
         dt = float(tmax)
     ms = dt / args.steps * 1e3
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
-    kern_flops = 2.0 * Mrows * (4 * D) * D
+    kern_flops = 2.0 * Mrows * (4 * W) * W
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     P = S - 1
-    step_flops = b * (3 * tower_fwd_flops(S, 1024, P, layers=args.layers) + tower_fwd_flops(50, 3072, 49, layers=args.layers)) \
-        + 6.0 * (b * world) ** 2 * E / world
+    step_flops = b * (3 * tower_fwd_flops(S, 1024, P, width=W, layers=args.layers)
+                      + tower_fwd_flops(50, 3072, 49, layers=min(args.layers, 12))) + 6.0 * (b * world) ** 2 * E / world
     out = {
         "metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"VA pretrain step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-B/{args.layers}L "
+        "config": {"workload": f"VA pretrain step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-{'B' if W == 768 else W}/{args.layers}L "
                                "fwd+bwd + frozen CLIP ViT-B/32 image tower fwd + InfoNCE + LARS (BASELINE.json configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",
                    "negatives": "global (all-gather)" if world > 1 else "global"},
         "loss": round(float(loss.detach()), 4),
         "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "roofline": {"bound": "mfma", "kernel": "%s (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (DOMINANT_KERNEL, Mrows, 4 * D, D),
+        "roofline": {"bound": "mfma", "kernel": "%s (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (DOMINANT_KERNEL, Mrows, 4 * W, W),
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * D, D), "traffic_source": PMC_FILE,
-                     "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * D + 4 * D * D + 2 * Mrows * 4 * D),
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * W, W), "traffic_source": PMC_FILE,
+                     "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * W + 4 * W * W + 2 * Mrows * 4 * W),
                      "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
     }
     if rank == 0:

@@ -370,3 +370,38 @@ def test_torch_optim_branch_adam_with_warmup():
     assert abs(mon.optimizer.param_groups[0]["lr"] - 1e-3 * 0.5) < 1e-12                    # one scheduler step past milestone 1
     moved = sum(int(not torch.equal(v.detach(), before[k])) for k, v in mon.model.named_parameters() if k in before)
     assert moved == len(before)
+
+
+def _va_step(extra):
+    from vipant_amd.config import compose
+    from vipant_amd.module import adjust_learning_rate
+    from vipant_amd.monitor import VAMonitor
+    ov = ("+running=bimodal worker=CVALP mode=dp eval=False num_gpus=1 +model/image=vit_val +model/audio=vit_val "
+          "+model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=2 running.audio.max_len=256 "
+          "running.audio.num_mel_bins=64 running.batch_size=24 running.epochs=2 "
+          "running.synthetic_steps=2 running.save_epoch=False optimizer.warmup_epoch=1").split() + extra
+    cfg = compose(ov)
+    cfg.rank = 0
+    torch.manual_seed(cfg.seed)
+    mon = VAMonitor(cfg, lambda *_: None, torch.device(DEV))
+    images, audios, text, _, _ = mon.make_batch(next(iter(mon.dataloader)))
+    adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, 1)
+    loss = mon.step(images, audios, None)
+    return float(loss.detach()), {k: v.detach().clone() for k, v in mon.model.named_parameters() if v.requires_grad}
+
+
+def test_activation_memory_plans_keep_the_step():
+    """`running.recompute_mlp` (the [M, 4D] MLP activations re-made in the backward by one more c_fc contraction) is bit-identical
+    to the plain step; `running.micro_batch` (towers 8 clips at a time under ONE 24-way loss, image tower included) gives the
+    same loss and the same parameters up to fp32 summation order of the weight gradients."""
+    l0, p0 = _va_step([])
+    l1, p1 = _va_step(["running.recompute_mlp=True"])
+    assert l0 == l1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    l2, p2 = _va_step(["running.micro_batch=8", "running.recompute_mlp=True"])
+    assert abs(l0 - l2) < 1e-6, (l0, l2)
+    for k in p0:
+        err = float((p0[k] - p2[k]).abs().max())
+        assert err <= 1e-6 + 1e-4 * float(p0[k].abs().max()), (k, err)

@@ -24,6 +24,9 @@ _running_common = {
     "train_samples": 1.0, "test_samples": 5000,
     # dataset-free operation (this build): synthetic spectrogram / token batches, SURVEY.md 8-D2
     "synthetic": True, "synthetic_steps": 8, "precomputed_image": False,
+    # activation-memory plan for batches that do not fit: towers in micro-batches under one global-batch loss,
+    # and / or the MLP activations recomputed in the backward
+    "micro_batch": 0, "recompute_mlp": False,
 }
 
 GROUPS = {

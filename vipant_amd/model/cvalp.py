@@ -29,6 +29,12 @@ class CVALP(nn.Module):
     # ------------------------------------------------------------------ forward (cvalp.py:34-62)
     def forward(self, images, audios, text, *args, **kwargs):
         kwargs = {"normalized": self.loss_head.normalized, "names": kwargs.get("names", None)}
+        return self.loss_from_features(*self.features(images, audios, text, **kwargs), **kwargs)
+
+    def features(self, images, audios, text, **kwargs):
+        """The three towers (cvalp.py:37-59) -> (image, audio, text) features, None for a modality that is absent or dummy.
+        Split from the loss so that the trainer can run the towers in micro-batches under one global-batch loss."""
+        kwargs = {"normalized": self.loss_head.normalized, "names": kwargs.get("names", None)}
         image_features = audio_features = text_features = None
         dummy_image = images is not None and list(images.shape[1:]) == [1, 1, 1]
         side = None
@@ -62,6 +68,10 @@ class CVALP(nn.Module):
             image_features = None                      # "dummy images will be ignored"
         if dummy_text and text is not None:
             text_features = None
+        return image_features, audio_features, text_features
+
+    def loss_from_features(self, image_features, audio_features, text_features, **kwargs):
+        kwargs = {"normalized": self.loss_head.normalized, "names": kwargs.get("names", None)}
         return self.loss_head(image_features, audio_features, text_features, **kwargs)
 
     @staticmethod

@@ -85,6 +85,10 @@ class Monitor(object):
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):
                     head.encoder.grad_sync = self.grad_sync
+        if cfg.running.get("recompute_mlp", False):
+            for head in (model.audio_head, model.image_head, model.text_head):
+                if head is not None and hasattr(head, "encoder"):
+                    head.encoder.recompute_mlp = True
         self.model.train(not cfg.eval)
         self.build_optimizer(tunable_params)
 
@@ -135,11 +139,42 @@ class Monitor(object):
             self.last_time = this_time
 
     # ------------------------------------------------------------------ one optimisation step
+    def _forward_backward_micro(self, images, audios, text, mb):
+        """One global-batch step with the towers run `mb` samples at a time (`running.micro_batch`), for batches whose
+        activations do not fit at once (BASELINE.json configs[4]: ViT-L, 1024 clips per GPU).  The objective is untouched --
+        every sample is still scored against the whole batch:
+          1. features of all micro-batches, nothing kept for a backward;
+          2. the loss over the concatenated features -> d loss / d features (and the loss head's own gradients);
+          3. every micro-batch again, this time kept, and back-propagated from its slice of (2).
+        The parameter gradients equal the one-pass gradients up to fp32 summation order; the price is one extra tower forward."""
+        n = audios.shape[0]
+        cuts = [(i, min(i + mb, n)) for i in range(0, n, mb)]
+        parts = []
+        with torch.no_grad():
+            for a, b in cuts:
+                parts.append(self.model.features(images[a:b], audios[a:b], text[a:b] if text is not None else None))
+        feats = [None if parts[0][m] is None else torch.cat([p[m] for p in parts]).detach() for m in range(3)]
+        heads = (self.model.image_head, self.model.audio_head, self.model.text_head)
+        live = [m for m in range(3) if feats[m] is not None and heads[m] is not None
+                and any(p.requires_grad for p in heads[m].parameters())]
+        for m in live:
+            feats[m].requires_grad_()
+        loss = self.model.loss_from_features(*feats)
+        loss.backward()
+        for a, b in cuts:
+            again = self.model.features(images[a:b], audios[a:b], text[a:b] if text is not None else None)
+            torch.autograd.backward([again[m] for m in live], [feats[m].grad[a:b] for m in live])
+        return loss
+
     def step(self, images, audios, text):
         """zero_grad -> forward -> backward -> (replica gradient reduction) -> optimizer (cvalp.py:200-205)."""
         self.optimizer.zero_grad(set_to_none=True)
-        loss = self.model(images, audios, text if self.with_text else None)
-        loss.backward()
+        mb = int(self.cfg.running.get("micro_batch", 0) or 0)
+        if 0 < mb < audios.shape[0]:
+            loss = self._forward_backward_micro(images, audios, text if self.with_text else None, mb)
+        else:
+            loss = self.model(images, audios, text if self.with_text else None)
+            loss.backward()
         if self.grad_sync is not None:
             rest = [p for p in self.params if not getattr(p, "_vipant_bucketed", False)]
             if self.model.loss_head is not None and self.cfg.running.get("negatives", "global") == "global":

@@ -304,7 +304,7 @@ class BackboneFn(torch.autograd.Function):
     activations and the (fp32, bf16) gradient-stream pair between layers are managed here, not by autograd."""
 
     @staticmethod
-    def forward(ctx, x, batch, S, causal, grad_sync, *params):
+    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, *params):
         _need(x, F32, "backbone.x")
         M, D = x.shape
         assert M == batch * S and len(params) % 12 == 0
@@ -330,7 +330,7 @@ class BackboneFn(torch.autograd.Function):
             if train:
                 wqkv_b, wqkv_t = cast_bf16(wqkv, True); wo_b, wo_t = cast_bf16(wo, True)
                 wfc_b, wfc_t = cast_bf16(wfc, True); wpr_b, wpr_t = cast_bf16(wpr, True)
-                wts.append((wqkv_t, wo_t, wfc_t, wpr_t))
+                wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None))
                 qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
                 u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
                 g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
@@ -349,21 +349,24 @@ class BackboneFn(torch.autograd.Function):
             gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
             gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             if train:
-                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g]
+                # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
+                # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
+                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2] + ([] if recompute_mlp else [u, g])
             x, y_prev = x1, y2
         x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
-            ctx.meta = (batch, S, bool(causal), L, H)
+            ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp))
             ctx.grad_sync = grad_sync
         return x
 
     @staticmethod
     def backward(ctx, dx_in):
-        batch, S, causal, L, H = ctx.meta
+        batch, S, causal, L, H, recompute_mlp = ctx.meta
         tensors = ctx.saved_tensors
-        saved, params = tensors[:13 * L], tensors[13 * L:]
+        ns = 11 if recompute_mlp else 13
+        saved, params = tensors[:ns * L], tensors[ns * L:]
         dev = dx_in.device
         dx = dx_in.contiguous()
         M, D = dx.shape
@@ -388,15 +391,23 @@ class BackboneFn(torch.autograd.Function):
             a.record_stream(side); b.record_stream(side)        # not handed to another tensor while the side stream reads
 
         for l in reversed(range(L)):
-            x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2, u, g = saved[13 * l:13 * l + 13]
-            ln1w, _, _, _, _, _, ln2w, _, _, _, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
-            wqkv_t, wo_t, wfc_t, wpr_t = ctx.wts[l]
+            x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
+            ln1w, _, _, _, _, _, ln2w, _, _, bfc, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
+            wqkv_t, wo_t, wfc_t, wpr_t, wfc_b = ctx.wts[l]
+            if recompute_mlp:
+                u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+                g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+                gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
+            else:
+                u, g = saved[ns * l + 11:ns * l + 13]
             (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
             lg_below = _LayerGrads([p.shape for p in params[12 * (l - 1):12 * l]], dev) if l > 0 else None
             # c_proj + QuickGELU'
             du = torch.empty((M, 4 * D), dtype=BF16, device=dev)
             gemm_nt(dx_b, wpr_t, du, aux=u, epi=EPI_DQUICKGELU)
             dweight(dx_b, g, d_wpr)
+            if recompute_mlp:
+                del u, g
             # c_fc
             dh2 = torch.empty((M, D), dtype=BF16, device=dev)
             gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
@@ -434,8 +445,8 @@ class BackboneFn(torch.autograd.Function):
             main.wait_stream(side)          # every weight gradient is complete before autograd hands them on
         ctx.wts = None
         need = ctx.needs_input_grad
-        out_grads = [gr if need[5 + i] else None for i, gr in enumerate(grads)]
-        return (dx if need[0] else None, None, None, None, None, *out_grads)
+        out_grads = [gr if need[6 + i] else None for i, gr in enumerate(grads)]
+        return (dx if need[0] else None, None, None, None, None, None, *out_grads)
 
 
 # ---------------------------------------------------------------------------------- read-out
