@@ -7,12 +7,16 @@
 //           (B * #tiles floats instead of B^2) plus the diagonal;
 //   final   two small kernels merge the triples into row / column log-sum-exp, the loss and d logit_scale
 //           ( = sum dZ * Z, expressible from the triples );
-//   pass 2  recomputes the tiles that touch this rank's row strip / column strip, forms
-//           s * dZ = s * (softmax_row + softmax_col - 2 I) / B in registers and stores it as bf16;
-//   grads   dx1 = (s dZ) x2 and dx2 = (s dZ)^T x1 reuse the NT / TN contraction kernels.
-// Precision: inputs are fp32; the logit contraction uses a hi/lo bf16 split (x = hi + lo, three MFMA terms
-// hi*hi + hi*lo + lo*hi concatenated along K) with fp32 accumulation, which keeps |dZ| below ~1e-5 relative and
-// the loss well inside the 1e-3 budget; exp / log in fp32.
+//   pass 2  recomputes the tiles that touch this rank's column strip, forms s * dZ = s * (softmax_row + softmax_col - 2 I) / B
+//           in registers and stores it as bf16 -- twice, the second launch with the two operands (and the two LSE vectors)
+//           swapped, which yields the same matrix TRANSPOSED without any transposing store;
+//   grads   dx2 = (s dZ)^T x1 and dx1 = (s dZ^T)^T x2 are then the same token-reduction (TN) contraction, split over all
+//           256 CUs (the row-major form of dx1, an NT contraction with 32 output tiles, left 7/8 of the chip idle).
+// Precision: inputs are fp32; pass 1 (the loss, the LSE vectors, d logit_scale) uses a hi/lo bf16 split of both operands
+// (x = hi + lo, three MFMA terms hi*hi + hi*lo + lo*hi concatenated along K) with fp32 accumulation: logits to ~1e-6, the
+// loss well inside the 1e-3 budget.  Pass 2 needs that only where softmax - I cancels, i.e. on the diagonal ELEMENTS, which reuse
+// pass 1's logits; everywhere else one bf16 term (K = E) moves a logit by ~2e-3 * s / 14, below the bf16 rounding of dZ itself.
+// exp / log in fp32.
 #include "nt_core.h"
 
 namespace {
@@ -20,7 +24,7 @@ namespace {
 using namespace ntcore;
 
 struct NceWs {       // carved out of the caller's workspace; all offsets 256-B aligned
-    bf16_t *x1cat, *x2cat, *x2t, *dz;
+    bf16_t *x1cat, *x2cat, *dz, *dzt;
     float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part;   // scal[0] = s, scal[1] = clamped
     void* tn_ws;
     size_t tn_bytes, total;
@@ -38,22 +42,22 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     auto take = [&](size_t bytes) { char* p = base + off; off += align256(bytes); return p; };
     w.x1cat = (bf16_t*)take((size_t)B * 3 * E * 2);
     w.x2cat = (bf16_t*)take((size_t)B * 3 * E * 2);
-    w.x2t = (bf16_t*)take((size_t)E * Bp * 2);
     w.dz = (bf16_t*)take((size_t)B * Bp * 2);
+    w.dzt = (bf16_t*)take((size_t)B * Bp * 2);
     w.rmax = (float*)take((size_t)w.rparts * B * 4); w.rsum = (float*)take((size_t)w.rparts * B * 4);
     w.rwz = (float*)take((size_t)w.rparts * B * 4);
     w.cmax = (float*)take((size_t)w.cparts * B * 4); w.csum = (float*)take((size_t)w.cparts * B * 4);
     w.cwz = (float*)take((size_t)w.cparts * B * 4);
     w.diag = (float*)take((size_t)B * 4); w.rlse = (float*)take((size_t)B * 4); w.clse = (float*)take((size_t)B * 4);
     w.scal = (float*)take(256);
-    w.part = (float*)take((size_t)ceil_div(B, 256) * 2 * 4);
+    w.part = (float*)take((size_t)ceil_div(B, 16) * 2 * 4);
     w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
     w.tn_ws = take(w.tn_bytes);
     w.total = off;
     return w;
 }
 
-// x -> [hi | hi | lo] (x1) or [hi | lo | hi] (x2), and x2 hi transposed with zero padding.
+// x -> [hi | hi | lo] (x1) or [hi | lo | hi] (x2).
 __global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                        const float* __restrict__ logit_scale, float scale_max, NceWs w,
                                                        int B, int E) {
@@ -74,11 +78,7 @@ __global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__
         bf16_t* p2 = w.x2cat + r * 3 * E + c;
         p1[0] = ah; p1[E] = ah; p1[2 * E] = al;
         p2[0] = th; p2[E] = tl; p2[2 * E] = th;
-        w.x2t[(int64_t)c * w.Bp + r] = th;
     }
-    const int pad = w.Bp - B;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)E * pad; i += (int64_t)gridDim.x * 256)
-        w.x2t[(i / pad) * w.Bp + B + (i % pad)] = (bf16_t)0.0f;
 }
 
 template <int PASS>
@@ -92,13 +92,15 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
     const int tile = xcd_remap(blockIdx.x, ntm * ntn);
     const int tm = tile / ntn, tn = tile % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
-    if (PASS == 2) {
-        const bool rows_hit = m0 < row0 + nrows && m0 + BM > row0;
+    if (PASS == 2) {      // only the column strip of this launch's matrix feeds a gradient of this rank's rows
         const bool cols_hit = n0 < row0 + nrows && n0 + BN > row0;
-        if (!rows_hit && !cols_hit) return;
+        if (!cols_hit) return;
     }
     f32x4 acc[8][4];
-    mainloop(smem, w.x1cat, K, B, w.x2cat, K, B, K, m0, n0, wave, lane, acc);
+    // K = 3E: [hi|hi|lo] . [hi|lo|hi]; pass 2: the first E columns only (hi . hi) -- its diagonal ELEMENTS, the only place where
+    // softmax - I cancels, take the fp32-grade logit pass 1 left in w.diag
+    const int Kt = PASS == 2 ? K / 3 : K;
+    mainloop(smem, w.x1cat, K, B, w.x2cat, K, B, Kt, m0, n0, wave, lane, acc);
     const float s = w.scal[0];
     const int mb = m0 + wm * 128 + frow, nb = n0 + wn * 64 + fq * 4;
 
@@ -185,11 +187,12 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
                 const int m = mb + i * 16;
                 if (m >= B) continue;
                 const float rl = w.rlse[m];
+                const float dg = tm == tn ? w.diag[m] : 0.f;
                 f32x4 d;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n4 + r;
-                    const float z = s * acc[i][j][r];
+                    const float z = m == n ? dg : s * acc[i][j][r];
                     const float g = (__expf(z - rl) + __expf(z - cl[r]) - (m == n ? 2.f : 0.f)) * k;
                     d[r] = n < B ? g * s : 0.f;
                 }
@@ -199,48 +202,69 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
     }
 }
 
-// Merge the per-tile triples: one thread per row/column index, 256 per workgroup; every workgroup leaves its two
-// partial sums in the workspace and a one-workgroup kernel adds them in a fixed order (reproducible).
+// Merge the per-tile triples.  A workgroup owns 16 row/column indices; thread t = (slice t >> 4, index t & 15) folds every
+// 16th partial of its index for both sides, the 16 slices of an index are combined through LDS in a fixed order
+// (reproducible), and the workgroup leaves its two partial sums for the one-workgroup kernel below.
 // loss = mean(rlse - d) + mean(clse - d);
 // dlogit_scale = gscale/B * (sum_i E_row[i] + sum_j E_col[j] - 2 sum_i d_i), zero when the scale is clamped.
 __global__ __launch_bounds__(256) void nce_merge_kernel(NceWs w, int B) {
-    __shared__ float red[2][256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float lsum = 0.f, esum = 0.f;
-    if (i < B) {
-        float acc2[2][2];
+    __shared__ float part[2][3][16][16];      // [side][max, sum, sum*z][slice][index]
+    __shared__ float red[2][16];
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const float* pm = side == 0 ? w.rmax : w.cmax;
-            const float* ps = side == 0 ? w.rsum : w.csum;
-            const float* pw = side == 0 ? w.rwz : w.cwz;
-            const int parts = side == 0 ? w.rparts : w.cparts;
-            float mx = -INFINITY;
-            for (int p = 0; p < parts; ++p) mx = fmaxf(mx, pm[(int64_t)p * B + i]);
-            float se = 0.f, sw = 0.f;
-            for (int p = 0; p < parts; ++p) {
+    for (int side = 0; side < 2; ++side) {
+        const float* pm = side == 0 ? w.rmax : w.cmax;
+        const float* ps = side == 0 ? w.rsum : w.csum;
+        const float* pw = side == 0 ? w.rwz : w.cwz;
+        const int parts = side == 0 ? w.rparts : w.cparts;
+        float mx = -INFINITY, se = 0.f, sw = 0.f;
+        if (i < B) {
+            for (int p = sl; p < parts; p += 16) {
                 const float pmx = pm[(int64_t)p * B + i];
                 if (pmx == -INFINITY) continue;
-                const float f = __expf(pmx - mx);
-                se += ps[(int64_t)p * B + i] * f;
-                sw += pw[(int64_t)p * B + i] * f;
+                const float nm = fmaxf(mx, pmx);
+                const float fo = mx == -INFINITY ? 0.f : __expf(mx - nm), fn = __expf(pmx - nm);
+                se = se * fo + ps[(int64_t)p * B + i] * fn;
+                sw = sw * fo + pw[(int64_t)p * B + i] * fn;
+                mx = nm;
             }
-            const float lse = mx + __logf(se);
-            (side == 0 ? w.rlse : w.clse)[i] = lse;
-            acc2[side][0] = lse;
-            acc2[side][1] = sw / se;
         }
-        const float d = w.diag[i];
-        lsum = (acc2[0][0] - d) + (acc2[1][0] - d);
-        esum = acc2[0][1] + acc2[1][1] - 2.f * d;
+        part[side][0][sl][il] = mx; part[side][1][sl][il] = se; part[side][2][sl][il] = sw;
     }
-    red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = esum;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-        __syncthreads();
+    if (threadIdx.x < 16) {
+        float lsum = 0.f, esum = 0.f;
+        if (i < B) {
+            float lse2[2], ez2[2];
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                float mx = -INFINITY;
+                for (int q = 0; q < 16; ++q) mx = fmaxf(mx, part[side][0][q][il]);
+                float se = 0.f, sw = 0.f;
+                for (int q = 0; q < 16; ++q) {
+                    const float pmx = part[side][0][q][il];
+                    if (pmx == -INFINITY) continue;
+                    const float f = __expf(pmx - mx);
+                    se += part[side][1][q][il] * f;
+                    sw += part[side][2][q][il] * f;
+                }
+                const float lse = mx + __logf(se);
+                (side == 0 ? w.rlse : w.clse)[i] = lse;
+                lse2[side] = lse; ez2[side] = sw / se;
+            }
+            const float d = w.diag[i];
+            lsum = (lse2[0] - d) + (lse2[1] - d);
+            esum = ez2[0] + ez2[1] - 2.f * d;
+        }
+        red[0][il] = lsum; red[1][il] = esum;
     }
-    if (threadIdx.x == 0) { w.part[2 * blockIdx.x] = red[0][0]; w.part[2 * blockIdx.x + 1] = red[1][0]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < 16; ++q) { a += red[0][q]; b += red[1][q]; }
+        w.part[2 * blockIdx.x] = a; w.part[2 * blockIdx.x + 1] = b;
+    }
 }
 
 __global__ __launch_bounds__(256) void nce_final_kernel(NceWs w, int B, int nparts, float gscale, float* loss, float* dls) {
@@ -289,21 +313,25 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_tile_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, 0, (int)B, 1.0f);
     VIPANT_LAUNCH_CHECK();
-    const int nparts = (int)ceil_div(B, 256);
+    const int nparts = (int)ceil_div(B, 16);
     hipLaunchKernelGGL(nce_merge_kernel, dim3((unsigned)nparts), dim3(256), 0, s, w, (int)B);
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(256), 0, s, w, (int)B, nparts, grad_scale, loss, dlogit_scale);
     VIPANT_LAUNCH_CHECK();
     if ((dx1 == nullptr && dx2 == nullptr) || nrows == 0) return VIPANT_OK;
-    hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)row0, (int)nrows, grad_scale);
-    VIPANT_LAUNCH_CHECK();
-    if (dx1 != nullptr) {
-        const int32_t e = vipant_gemm_nt((const uint16_t*)(w.dz + row0 * w.Bp), w.Bp, (const uint16_t*)w.x2t, w.Bp, dx1, E,
-                                         nullptr, nullptr, 1.0f, nrows, E, w.Bp, VIPANT_EPI_F32, stream);
+    if (dx2 != nullptr) {     // s dZ [m][n], columns n in the strip;  dx2[n, :] = sum_m s dZ[m][n] x1[m, :]
+        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)row0, (int)nrows, grad_scale);
+        VIPANT_LAUNCH_CHECK();
+        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + row0), w.Bp, (const uint16_t*)w.x1cat, 3 * E, dx2, E, B,
+                                         nrows, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
     }
-    if (dx2 != nullptr) {
-        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + row0), w.Bp, (const uint16_t*)w.x1cat, 3 * E, dx2, E, B,
+    if (dx1 != nullptr) {     // the same kernel on (x2, x1) with the LSE vectors swapped writes s dZ^T [n][m], columns m in the strip
+        NceWs t = w;
+        t.x1cat = w.x2cat; t.x2cat = w.x1cat; t.rlse = w.clse; t.clse = w.rlse; t.dz = w.dzt;
+        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)row0, (int)nrows, grad_scale);
+        VIPANT_LAUNCH_CHECK();
+        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dzt + row0), w.Bp, (const uint16_t*)w.x2cat, 3 * E, dx1, E, B,
                                          nrows, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
     }
