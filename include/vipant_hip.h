@@ -182,6 +182,95 @@ int32_t vipant_lars_step(float* const* p, const float* const* g, float* const* m
                          const int32_t* adapt, const float* lr, int64_t ntensors, float weight_decay,
                          float momentum, float eta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ==== The fused operator set: one entry point per reference operator group, forward and backward ==========
+ * Host-side compositions of the kernels above (vipant_amd/csrc/block.hip): same stream, no allocation, no synchronisation.
+ * Fusion plan: a residual add rides on the NEXT LayerNorm pass (`add` bf16 [M,D] = the previous branch output, `x_out` fp32
+ * [M,D] = x + add, both NULL for the first block); QuickGELU / QuickGELU' are epilogues of the c_fc / c_proj^T contractions;
+ * bias gradients are column sums taken inside the weight-gradient contraction or inside the LayerNorm backward (`dx_colsum`).
+ * Weights are bf16 copies of the fp32 parameters: `w` as stored ([out, in]), `w_t` transposed ([in, out]).
+ * `workspace` of the backward entry points: vipant_block_workspace_bytes(M, D) bytes, 256-byte aligned. */
+size_t vipant_block_workspace_bytes(int64_t M, int64_t D);
+
+/* K2 -- ln_1 + packed in_proj of nn.MultiheadAttention (cvap/module/val.py:519-520, 500; clip/model.py:154-160).
+ * h bf16 [M,D] = LN(x (+ add)), mean / rstd fp32 [M], qkv bf16 [M,3D] = h . w_qkv^T + b_qkv. */
+int32_t vipant_ln_qkv_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+                          const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd, uint16_t* qkv,
+                          int64_t M, int64_t D, void* stream);
+/* dstream fp32 [M,D]: in = gradient of the residual stream after this block's attention branch, out = gradient before the block
+ * (in place); dx_bf16 its bf16 copy; dh bf16 [M,D] scratch; dw fp32 [3D,D], db fp32 [3D], dgamma / dbeta fp32 [D];
+ * dx_colsum (optional fp32 [D]) = column sums of the produced gradient (= d c_proj.bias of the block below). */
+int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x, const float* mean,
+                          const float* rstd, const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* dh, float* dw,
+                          float* db, float* dgamma, float* dbeta, float* dx_colsum, int64_t M, int64_t D, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* K4 -- out_proj (cvap/module/val.py:517, 520).  residual == NULL: out bf16 [M,N] = a . w^T + bias (the step's form: the add
+ * happens in the next LayerNorm pass); residual fp32 [M,N]: out fp32 [M,N] = a . w^T + bias + residual (stand-alone form). */
+int32_t vipant_gemm_bias_residual_fwd(const uint16_t* a, const uint16_t* w, const float* bias, const float* residual, void* out,
+                                      int64_t M, int64_t N, int64_t K, void* stream);
+/* da bf16 [M,K] = dy . w (w_t = w^T, [K,N]); dw fp32 [N,K] = dy^T a.  (d bias = column sums of dy: see dx_colsum above.) */
+int32_t vipant_gemm_bias_residual_bwd(const uint16_t* dy, const uint16_t* w_t, const uint16_t* a, uint16_t* da, float* dw,
+                                      int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K5 -- ln_2 + c_fc + QuickGELU + c_proj (cvap/module/val.py:502-506, 521; clip/model.py:163-165).
+ * h bf16 [M,D] = LN(x (+ add)); u bf16 [M,4D] = h . w_fc^T + b_fc; g = u * sigmoid(1.702 u); y bf16 [M,D] = g . w_proj^T + b_proj. */
+int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+                                    const uint16_t* w_fc, const float* b_fc, const uint16_t* w_proj, const float* b_proj,
+                                    uint16_t* h, float* mean, float* rstd, uint16_t* u, uint16_t* g, uint16_t* y, int64_t M,
+                                    int64_t D, void* stream);
+/* u, g again from the saved h (activation-memory plan `running.recompute_mlp`). */
+int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint16_t* u, uint16_t* g,
+                                       int64_t M, int64_t D, void* stream);
+/* dy bf16 [M,D] = gradient of the MLP branch output (= bf16 copy of the stream gradient); dstream as in vipant_ln_qkv_bwd;
+ * du bf16 [M,4D], dh bf16 [M,D] scratch; dw_proj fp32 [D,4D], dw_fc fp32 [4D,D], db_fc fp32 [4D];
+ * dx_colsum (optional fp32 [D]) = d out_proj.bias. */
+int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t, const uint16_t* u,
+                                    const uint16_t* g, const uint16_t* h, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* du, uint16_t* dh,
+                                    float* dw_proj, float* dw_fc, float* db_fc, float* dgamma, float* dbeta, float* dx_colsum,
+                                    int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K1 -- ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + contraction, cls token, positional table,
+ * ln_pre.  x fp32 [b,C,T,F]; conv_w fp32 [Dw,Cw,ph,pw] (mean_channels != 0: the Cw stored channels are averaged, val.py:236-244);
+ * scratch / saved: w_eff bf16 [Dw,kcols], patches bf16 [b*P,kcols], pe fp32 [b*P,Dw], tokens fp32 [b*S,Dw] (kcols =
+ * (mean_channels ? 1 : Cw)*ph*pw, P = nrow*ncol, S = P+1); out fp32 [b*S,Dw] = the residual stream; mean / rstd fp32 [b*S]. */
+int32_t vipant_patch_embed_ln_fwd(const float* x, const float* conv_w, const float* cls, const float* pos, const float* gamma,
+                                  const float* beta, uint16_t* w_eff, uint16_t* patches, float* pe, float* tokens, float* out,
+                                  float* mean, float* rstd, int64_t b, int64_t C, int64_t T, int64_t F, int64_t Dw, int64_t Cw,
+                                  int64_t ph, int64_t pw, int64_t sh, int64_t sw, int32_t mean_channels, void* stream);
+size_t vipant_patch_embed_ln_bwd_workspace_bytes(int64_t b, int64_t P, int64_t Dw, int64_t kcols);
+/* dtokens fp32 [b*S,Dw], dpatches bf16 [b*P,Dw], dw_eff fp32 [Dw,kcols] scratch; dconv fp32 [Dw,Cw,khw] (mean_channels; else
+ * dw_eff IS the weight gradient); dcls fp32 [Dw]; dpos fp32 [rows >= S, Dw] must arrive zeroed. */
+int32_t vipant_patch_embed_ln_bwd(const float* dout, const float* tokens, const float* mean, const float* rstd, const float* gamma,
+                                  const uint16_t* patches, float* dtokens, uint16_t* dpatches, float* dw_eff, float* dconv,
+                                  float* dcls, float* dpos, float* dgamma, float* dbeta, int64_t b, int64_t P, int64_t Dw,
+                                  int64_t Cw, int64_t khw, int32_t mean_channels, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
+/* K6 -- ViTPostEncoder.forward + MetaHead's normalisation (cvap/module/val.py:288-289, clip_head.py:117-118):
+ * feat fp32 [batch,E] = LN(x[b, idx_b]) . proj (proj_t = proj^T bf16 [E,D]); idx == NULL reads row 0 (cls) in place, else the
+ * rows are gathered into `rows` fp32 [batch,D]; normalized != 0: out = feat / |feat|, norm fp32 [batch] (else out is unused). */
+int32_t vipant_cls_ln_proj_l2norm_fwd(const float* x, const int64_t* idx, const float* gamma, const float* beta,
+                                      const uint16_t* proj_t, float* rows, uint16_t* y, float* mean, float* rstd, float* feat,
+                                      float* out, float* norm, int64_t batch, int64_t S, int64_t D, int64_t E, int32_t normalized,
+                                      void* stream);
+size_t vipant_cls_ln_proj_l2norm_bwd_workspace_bytes(int64_t batch, int64_t D, int64_t E);
+/* dout fp32 [batch,E]; proj bf16 [D,E]; dfeat bf16 [batch,E], dy bf16 [batch,D], drows fp32 [batch,D] scratch; dx fp32 [batch*S,D]
+ * zeroed by the caller; dproj fp32 [D,E]. */
+int32_t vipant_cls_ln_proj_l2norm_bwd(const float* dout, const float* out, const float* norm, const float* x, const int64_t* idx,
+                                      const float* rows, const uint16_t* y, const float* mean, const float* rstd,
+                                      const float* gamma, const uint16_t* proj, uint16_t* dfeat, uint16_t* dy, float* drows,
+                                      float* dx, float* dproj, float* dgamma, float* dbeta, int64_t batch, int64_t S, int64_t D,
+                                      int64_t E, int32_t normalized, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K7 -- GPTPreEncoder.forward (cvap/module/val.py:109-122) and GPTPostEncoder.forward (val.py:136-146) of the frozen text tower. */
+int32_t vipant_embed_gather_pos_fwd(const int64_t* tokens, const float* table, const float* pos, float* x, int64_t* eot,
+                                    int64_t b, int64_t L, int64_t D, void* stream);
+int32_t vipant_eot_ln_proj_l2norm_fwd(const float* x, const int64_t* eot, const float* gamma, const float* beta,
+                                      const uint16_t* proj_t, float* rows, uint16_t* y, float* mean, float* rstd, float* feat,
+                                      float* out, float* norm, int64_t batch, int64_t L, int64_t D, int64_t E, int32_t normalized,
+                                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,23 @@ PROTOTYPES = {
     "vipant_retrieval_ranks": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_fbank_workspace_bytes": (_sz, [_i64]),
     "vipant_fbank": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _f32, _p, _sz, _p]),
+    # fused operator set (vipant_amd/csrc/block.hip)
+    "vipant_block_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_ln_qkv_fwd": (_i32, [_p] * 11 + [_i64, _i64, _p]),
+    "vipant_ln_qkv_bwd": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p]),
+    "vipant_gemm_bias_residual_fwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p]),
+    "vipant_gemm_bias_residual_bwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _sz, _p]),
+    "vipant_ln_mlp_quickgelu_fwd": (_i32, [_p] * 15 + [_i64, _i64, _p]),
+    "vipant_mlp_quickgelu_recompute": (_i32, [_p] * 5 + [_i64, _i64, _p]),
+    "vipant_ln_mlp_quickgelu_bwd": (_i32, [_p] * 20 + [_i64, _i64, _p, _sz, _p]),
+    "vipant_patch_embed_ln_fwd": (_i32, [_p] * 13 + [_i64] * 10 + [_i32, _p]),
+    "vipant_patch_embed_ln_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vipant_patch_embed_ln_bwd": (_i32, [_p] * 14 + [_i64] * 5 + [_i32, _p, _sz, _p]),
+    "vipant_cls_ln_proj_l2norm_fwd": (_i32, [_p] * 12 + [_i64] * 4 + [_i32, _p]),
+    "vipant_cls_ln_proj_l2norm_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vipant_cls_ln_proj_l2norm_bwd": (_i32, [_p] * 18 + [_i64] * 4 + [_i32, _p, _sz, _p]),
+    "vipant_embed_gather_pos_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_eot_ln_proj_l2norm_fwd": (_i32, [_p] * 12 + [_i64] * 4 + [_i32, _p]),
     "vipant_lars_workspace_bytes": (_sz, [_i64]),
     "vipant_lars_step": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _p, _sz, _p]),
 }

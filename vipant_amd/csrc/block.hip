@@ -1,0 +1,216 @@
+// The fused operator set of the C ABI (SURVEY.md 8b, row B-c): one entry point per reference operator group of the step --
+// K1 patch embedding + ln_pre, K2 ln_1 + packed QKV projection, K4 out_proj, K5 ln_2 + c_fc + QuickGELU + c_proj, K6 / K7
+// read-outs -- forward and backward each.  Every function here is host code only: it validates its arguments and enqueues the
+// kernels of this library (gemm_nt.hip, gemm_tn.hip, layernorm.hip, elementwise.hip) on the caller's stream, in the order and
+// with the fusion plan described in DESIGN.md section 5:
+//   * a residual add is never an epilogue of the contraction that produces the branch -- it rides on the NEXT LayerNorm pass
+//     (`add` / `x_out`), which reads and writes the fp32 stream anyway;
+//   * QuickGELU and its derivative are epilogues of the c_fc / c_proj^T contractions;
+//   * bias gradients come for free: column sums of dY inside the weight-gradient contraction (in_proj, c_fc) or inside the
+//     LayerNorm backward that produces dY (out_proj, c_proj: `dx_colsum`).
+// No allocation, no synchronisation; scratch activations and the split-reduction workspace are the caller's.
+#include "common.h"
+
+namespace {
+
+size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+#define TRY(expr)                      \
+    do {                               \
+        const int32_t _rc = (expr);    \
+        if (_rc != VIPANT_OK) return _rc; \
+    } while (0)
+
+}  // namespace
+
+extern "C" size_t vipant_block_workspace_bytes(int64_t M, int64_t D) {
+    size_t w = vipant_gemm_tn_workspace_bytes(M, 3 * D, D);
+    w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, 4 * D, D));
+    w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, 4 * D));
+    w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, D));
+    return max_sz(w, vipant_layernorm_bwd_workspace_bytes(M, D));
+}
+
+// ------------------------------------------------------------------------------------------------ K2: ln_1 + in_proj
+extern "C" int32_t vipant_ln_qkv_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+                                     const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd,
+                                     uint16_t* qkv, int64_t M, int64_t D, void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
+    VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_qkv_fwd: add and x_out go together");
+    TRY(vipant_layernorm_fwd(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, stream));
+    return vipant_gemm_nt(h, D, w_qkv, D, qkv, 3 * D, b_qkv, nullptr, 1.0f, M, 3 * D, D, VIPANT_EPI_BF16, stream);
+}
+
+extern "C" int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x,
+                                     const float* mean, const float* rstd, const float* gamma, float* dstream,
+                                     uint16_t* dx_bf16, uint16_t* dh, float* dw, float* db, float* dgamma, float* dbeta,
+                                     float* dx_colsum, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
+    VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE, "ln_qkv_bwd: workspace too small");
+    // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D])
+    TRY(vipant_gemm_nt(dqkv, 3 * D, w_qkv_t, 3 * D, dh, D, nullptr, nullptr, 1.0f, M, D, 3 * D, VIPANT_EPI_BF16, stream));
+    // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
+    TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
+    // ln_1 backward + residual-gradient add, in place on the stream gradient
+    return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
+                                D, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ K4: out_proj
+extern "C" int32_t vipant_gemm_bias_residual_fwd(const uint16_t* a, const uint16_t* w, const float* bias,
+                                                 const float* residual, void* out, int64_t M, int64_t N, int64_t K,
+                                                 void* stream) {
+    if (residual != nullptr)        // stand-alone form: out fp32 = a . w^T + bias + residual
+        return vipant_gemm_nt(a, K, w, K, out, N, bias, const_cast<float*>(residual), 1.0f, M, N, K, VIPANT_EPI_RESIDUAL_F32,
+                              stream);
+    // the step's form: branch output as bf16; the add happens in the next LayerNorm pass
+    return vipant_gemm_nt(a, K, w, K, out, N, bias, nullptr, 1.0f, M, N, K, VIPANT_EPI_BF16, stream);
+}
+
+extern "C" int32_t vipant_gemm_bias_residual_bwd(const uint16_t* dy, const uint16_t* w_t, const uint16_t* a, uint16_t* da,
+                                                 float* dw, int64_t M, int64_t N, int64_t K, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(workspace_bytes >= vipant_gemm_tn_workspace_bytes(M, N, K), VIPANT_ENOWORKSPACE,
+                   "gemm_bias_residual_bwd: workspace too small");
+    // da[M, K] = dy[M, N] . W[N, K]   (w_t is W^T, [K, N]);  dW[N, K] = dy^T a
+    TRY(vipant_gemm_nt(dy, N, w_t, N, da, K, nullptr, nullptr, 1.0f, M, K, N, VIPANT_EPI_BF16, stream));
+    return vipant_gemm_tn(dy, N, a, K, dw, K, M, N, K, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ K5: ln_2 + MLP
+extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma,
+                                               const float* beta, const uint16_t* w_fc, const float* b_fc,
+                                               const uint16_t* w_proj, const float* b_proj, uint16_t* h, float* mean,
+                                               float* rstd, uint16_t* u, uint16_t* g, uint16_t* y, int64_t M, int64_t D,
+                                               void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
+    VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: add and x_out go together");
+    TRY(vipant_layernorm_fwd(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, stream));
+    TRY(vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, u, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU, stream));
+    return vipant_gemm_nt(g, 4 * D, w_proj, 4 * D, y, D, b_proj, nullptr, 1.0f, M, D, 4 * D, VIPANT_EPI_BF16, stream);
+}
+
+// The [M, 4D] activations u, g alone, from the saved LayerNorm output (`running.recompute_mlp`: they were not kept).
+extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint16_t* u,
+                                                  uint16_t* g, int64_t M, int64_t D, void* stream) {
+    return vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, u, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU, stream);
+}
+
+extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t,
+                                               const uint16_t* u, const uint16_t* g, const uint16_t* h, const float* x,
+                                               const float* mean, const float* rstd, const float* gamma, float* dstream,
+                                               uint16_t* dx_bf16, uint16_t* du, uint16_t* dh, float* dw_proj, float* dw_fc,
+                                               float* db_fc, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
+                                               int64_t D, void* workspace, size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
+    VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE,
+                   "ln_mlp_quickgelu_bwd: workspace too small");
+    // du = (dy . W_proj) * QuickGELU'(u);  dW_proj = dy^T g   (d b_proj is the column sum the caller already has)
+    TRY(vipant_gemm_nt(dy, D, w_proj_t, D, du, 4 * D, nullptr, const_cast<uint16_t*>(u), 1.0f, M, 4 * D, D,
+                       VIPANT_EPI_DQUICKGELU, stream));
+    TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
+    // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
+    TRY(vipant_gemm_nt(du, 4 * D, w_fc_t, 4 * D, dh, D, nullptr, nullptr, 1.0f, M, D, 4 * D, VIPANT_EPI_BF16, stream));
+    TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
+    // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
+    return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
+                                D, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ K1: patch embedding + ln_pre
+extern "C" int32_t vipant_patch_embed_ln_fwd(const float* x, const float* conv_w, const float* cls, const float* pos,
+                                             const float* gamma, const float* beta, uint16_t* w_eff, uint16_t* patches,
+                                             float* pe, float* tokens, float* out, float* mean, float* rstd, int64_t b,
+                                             int64_t C, int64_t T, int64_t F, int64_t Dw, int64_t Cw, int64_t ph, int64_t pw,
+                                             int64_t sh, int64_t sw, int32_t mean_channels, void* stream) {
+    const int64_t nrow = (T - ph) / sh + 1, ncol = (F - pw) / sw + 1;
+    const int64_t P = nrow * ncol, S = P + 1;
+    const int64_t kcols = (mean_channels ? 1 : Cw) * ph * pw;
+    VIPANT_REQUIRE(nrow > 0 && ncol > 0 && kcols % 64 == 0, VIPANT_EBADSHAPE, "patch_embed_ln_fwd: bad geometry");
+    TRY(vipant_conv_weight_prep(conv_w, w_eff, Dw, Cw, ph * pw, mean_channels, stream));
+    TRY(vipant_im2col(x, patches, b, C, T, F, ph, pw, sh, sw, stream));
+    TRY(vipant_gemm_nt(patches, kcols, w_eff, kcols, pe, Dw, nullptr, nullptr, 1.0f, b * P, Dw, kcols, VIPANT_EPI_F32, stream));
+    TRY(vipant_assemble_tokens(pe, cls, pos, tokens, b, P, Dw, stream));
+    return vipant_layernorm_fwd(tokens, Dw, gamma, beta, nullptr, out, mean, rstd, b * S, Dw, nullptr, nullptr, stream);
+}
+
+extern "C" size_t vipant_patch_embed_ln_bwd_workspace_bytes(int64_t b, int64_t P, int64_t Dw, int64_t kcols) {
+    return max_sz(vipant_gemm_tn_workspace_bytes(b * P, Dw, kcols), vipant_layernorm_bwd_workspace_bytes(b * (P + 1), Dw));
+}
+
+extern "C" int32_t vipant_patch_embed_ln_bwd(const float* dout, const float* tokens, const float* mean, const float* rstd,
+                                             const float* gamma, const uint16_t* patches, float* dtokens, uint16_t* dpatches,
+                                             float* dw_eff, float* dconv, float* dcls, float* dpos, float* dgamma,
+                                             float* dbeta, int64_t b, int64_t P, int64_t Dw, int64_t Cw, int64_t khw,
+                                             int32_t mean_channels, void* workspace, size_t workspace_bytes, void* stream) {
+    const int64_t kcols = (mean_channels ? 1 : Cw) * khw;
+    VIPANT_REQUIRE(workspace_bytes >= vipant_patch_embed_ln_bwd_workspace_bytes(b, P, Dw, kcols), VIPANT_ENOWORKSPACE,
+                   "patch_embed_ln_bwd: workspace too small");
+    TRY(vipant_layernorm_bwd(dout, 1, tokens, Dw, mean, rstd, gamma, nullptr, dtokens, Dw, nullptr, dgamma, dbeta, nullptr, 0,
+                             b * (P + 1), Dw, workspace, workspace_bytes, stream));
+    TRY(vipant_assemble_tokens_bwd(dtokens, dpatches, dcls, dpos, 0, b, P, Dw, stream));    // dpos must arrive zeroed
+    TRY(vipant_gemm_tn(dpatches, Dw, patches, kcols, dw_eff, kcols, b * P, Dw, kcols, 0, nullptr, workspace, workspace_bytes,
+                       stream));
+    if (mean_channels) return vipant_conv_weight_grad(dw_eff, dconv, Dw, Cw, khw, 0, stream);
+    return VIPANT_OK;       // dconv == dw_eff viewed as [Dw, Cw, kh, kw]
+}
+
+// ------------------------------------------------------------------------------------------------ K6 / K7: read-outs
+// LN(x[b, row_b]) @ proj (+ L2 normalisation): row_b = 0 (cls, ViTPostEncoder) when idx == NULL, else idx[b] (EOT, GPTPostEncoder).
+extern "C" int32_t vipant_cls_ln_proj_l2norm_fwd(const float* x, const int64_t* idx, const float* gamma, const float* beta,
+                                                 const uint16_t* proj_t, float* rows, uint16_t* y, float* mean, float* rstd,
+                                                 float* feat, float* out, float* norm, int64_t batch, int64_t S, int64_t D,
+                                                 int64_t E, int32_t normalized, void* stream) {
+    const float* src = x;
+    int64_t ld = S * D;                       // cls row of every sample: strided view, no copy
+    if (idx != nullptr) {
+        VIPANT_REQUIRE(rows != nullptr, VIPANT_EBADSHAPE, "cls_ln_proj_l2norm_fwd: gathered read-out needs `rows`");
+        TRY(vipant_gather_rows(x, idx, rows, batch, S, D, stream));
+        src = rows; ld = D;
+    }
+    TRY(vipant_layernorm_fwd(src, ld, gamma, beta, y, nullptr, mean, rstd, batch, D, nullptr, nullptr, stream));
+    TRY(vipant_gemm_nt(y, D, proj_t, D, feat, E, nullptr, nullptr, 1.0f, batch, E, D, VIPANT_EPI_F32, stream));
+    if (normalized) return vipant_l2norm_fwd(feat, out, norm, batch, E, stream);
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_eot_ln_proj_l2norm_fwd(const float* x, const int64_t* eot, const float* gamma, const float* beta,
+                                                 const uint16_t* proj_t, float* rows, uint16_t* y, float* mean, float* rstd,
+                                                 float* feat, float* out, float* norm, int64_t batch, int64_t L, int64_t D,
+                                                 int64_t E, int32_t normalized, void* stream) {
+    VIPANT_REQUIRE(eot != nullptr, VIPANT_EBADSHAPE, "eot_ln_proj_l2norm_fwd: eot indices are required");
+    return vipant_cls_ln_proj_l2norm_fwd(x, eot, gamma, beta, proj_t, rows, y, mean, rstd, feat, out, norm, batch, L, D, E,
+                                         normalized, stream);
+}
+
+extern "C" size_t vipant_cls_ln_proj_l2norm_bwd_workspace_bytes(int64_t batch, int64_t D, int64_t E) {
+    return max_sz(vipant_gemm_tn_workspace_bytes(batch, D, E), vipant_layernorm_bwd_workspace_bytes(batch, D));
+}
+
+// dx (token-major, zeroed by the caller) receives the read-out rows' gradient; dproj [D, E] = y^T dfeat.
+extern "C" int32_t vipant_cls_ln_proj_l2norm_bwd(const float* dout, const float* out, const float* norm, const float* x,
+                                                 const int64_t* idx, const float* rows, const uint16_t* y, const float* mean,
+                                                 const float* rstd, const float* gamma, const uint16_t* proj, uint16_t* dfeat,
+                                                 uint16_t* dy, float* drows, float* dx, float* dproj, float* dgamma,
+                                                 float* dbeta, int64_t batch, int64_t S, int64_t D, int64_t E,
+                                                 int32_t normalized, void* workspace, size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(workspace_bytes >= vipant_cls_ln_proj_l2norm_bwd_workspace_bytes(batch, D, E), VIPANT_ENOWORKSPACE,
+                   "cls_ln_proj_l2norm_bwd: workspace too small");
+    if (normalized) TRY(vipant_l2norm_bwd(dout, out, norm, nullptr, dfeat, batch, E, stream));
+    else TRY(vipant_cast_bf16(dout, dfeat, nullptr, 1, batch * E, stream));
+    TRY(vipant_gemm_nt(dfeat, E, proj, E, dy, D, nullptr, nullptr, 1.0f, batch, D, E, VIPANT_EPI_BF16, stream));   // dy = dfeat . proj^T
+    TRY(vipant_gemm_tn(y, D, dfeat, E, dproj, E, batch, D, E, 0, nullptr, workspace, workspace_bytes, stream));
+    if (idx == nullptr)
+        return vipant_layernorm_bwd(dy, 0, x, S * D, mean, rstd, gamma, nullptr, dx, S * D, nullptr, dgamma, dbeta, nullptr, 0,
+                                    batch, D, workspace, workspace_bytes, stream);
+    TRY(vipant_layernorm_bwd(dy, 0, rows, D, mean, rstd, gamma, nullptr, drows, D, nullptr, dgamma, dbeta, nullptr, 0, batch, D,
+                             workspace, workspace_bytes, stream));
+    return vipant_scatter_rows(drows, idx, dx, batch, S, D, stream);
+}
+
+// GPTPreEncoder.forward (val.py:109-122): the export-set name of vipant_embed_tokens.
+extern "C" int32_t vipant_embed_gather_pos_fwd(const int64_t* tokens, const float* table, const float* pos, float* x,
+                                               int64_t* eot, int64_t b, int64_t L, int64_t D, void* stream) {
+    return vipant_embed_tokens(tokens, table, pos, x, eot, b, L, D, stream);
+}

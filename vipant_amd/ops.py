@@ -9,7 +9,6 @@ The residual stream and its gradient are fp32; every MFMA operand is bf16 (fp32 
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -213,7 +212,7 @@ def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
 # ---------------------------------------------------------------------------------- patch embedding
 class PatchEmbedFn(torch.autograd.Function):
     """ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + MFMA contraction, cls token,
-    positional table, ln_pre.  x fp32 [b, C, T, F] -> residual stream fp32 [b*S, D]."""
+    positional table, ln_pre -- vipant_patch_embed_ln_{fwd,bwd}.  x fp32 [b, C, T, F] -> residual stream fp32 [b*S, D]."""
 
     @staticmethod
     def forward(ctx, x, conv_w, cls, pos, ln_w, ln_b, stride):
@@ -231,16 +230,16 @@ class PatchEmbedFn(torch.autograd.Function):
         kcols = (1 if mean_ch else Cw) * ph * pw
         dev = x.device
         w_eff = torch.empty((D, kcols), dtype=BF16, device=dev)
-        call("vipant_conv_weight_prep", conv_w.detach().contiguous().data_ptr(), w_eff.data_ptr(), D, Cw, ph * pw,
-             int(mean_ch), _stream())
         patches = torch.empty((b * P, kcols), dtype=BF16, device=dev)
-        call("vipant_im2col", x.data_ptr(), patches.data_ptr(), b, Cx, T, Fq, ph, pw, sh, sw, _stream())
         pe = torch.empty((b * P, D), dtype=F32, device=dev)
-        gemm_nt(patches, w_eff, pe, epi=EPI_F32)
         tok = torch.empty((b * S, D), dtype=F32, device=dev)
-        call("vipant_assemble_tokens", pe.data_ptr(), cls.detach().contiguous().data_ptr(),
-             pos.detach().contiguous().data_ptr(), tok.data_ptr(), b, P, D, _stream())
-        _, out, mean, rstd = layernorm_fwd(tok, ln_w.detach(), ln_b.detach(), want_bf16=False, want_f32=True)
+        out = torch.empty((b * S, D), dtype=F32, device=dev)
+        mean = torch.empty((b * S,), dtype=F32, device=dev)
+        rstd = torch.empty((b * S,), dtype=F32, device=dev)
+        call("vipant_patch_embed_ln_fwd", x.data_ptr(), conv_w.detach().contiguous().data_ptr(),
+             cls.detach().contiguous().data_ptr(), pos.detach().contiguous().data_ptr(), ln_w.detach().data_ptr(),
+             ln_b.detach().data_ptr(), w_eff.data_ptr(), patches.data_ptr(), pe.data_ptr(), tok.data_ptr(), out.data_ptr(),
+             mean.data_ptr(), rstd.data_ptr(), b, Cx, T, Fq, D, Cw, ph, pw, sh, sw, int(mean_ch), _stream())
         ctx.save_for_backward(patches, tok, mean, rstd, ln_w)
         ctx.meta = (b, P, D, Cw, ph * pw, mean_ch, tuple(conv_w.shape), tuple(pos.shape))
         return out
@@ -251,22 +250,20 @@ class PatchEmbedFn(torch.autograd.Function):
         b, P, D, Cw, khw, mean_ch, conv_shape, pos_shape = ctx.meta
         dev = dout.device
         dout = dout.contiguous()
+        kcols = patches.shape[1]
         dtok = torch.empty_like(tok)
-        dlnw = torch.empty((D,), dtype=F32, device=dev)
-        dlnb = torch.empty((D,), dtype=F32, device=dev)
-        layernorm_bwd(dout, tok, mean, rstd, ln_w.detach(), dx=dtok, dgamma=dlnw, dbeta=dlnb)
         dpatch = torch.empty((b * P, D), dtype=BF16, device=dev)
+        dw_eff = torch.empty((D, kcols), dtype=F32, device=dev)
+        dconv = torch.empty(conv_shape, dtype=F32, device=dev) if mean_ch else dw_eff.view(conv_shape)
         dcls = torch.empty((D,), dtype=F32, device=dev)
         dpos = torch.zeros(pos_shape, dtype=F32, device=dev)
-        call("vipant_assemble_tokens_bwd", dtok.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), 0, b, P,
-             D, _stream())
-        dw_eff = torch.empty((D, patches.shape[1]), dtype=F32, device=dev)
-        gemm_tn(dpatch, patches, dw_eff)
-        if mean_ch:
-            dconv = torch.empty(conv_shape, dtype=F32, device=dev)
-            call("vipant_conv_weight_grad", dw_eff.data_ptr(), dconv.data_ptr(), D, Cw, khw, 0, _stream())
-        else:
-            dconv = dw_eff.view(conv_shape)
+        dlnw = torch.empty((D,), dtype=F32, device=dev)
+        dlnb = torch.empty((D,), dtype=F32, device=dev)
+        ws = scratch("patch_embed_bwd", query("vipant_patch_embed_ln_bwd_workspace_bytes", b, P, D, kcols), dev)
+        call("vipant_patch_embed_ln_bwd", dout.data_ptr(), tok.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+             ln_w.detach().data_ptr(), patches.data_ptr(), dtok.data_ptr(), dpatch.data_ptr(), dw_eff.data_ptr(),
+             dconv.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), b, P, D, Cw, khw,
+             int(mean_ch), ws.data_ptr(), ws.numel(), _stream())
         return None, dconv, dcls, dpos, dlnw, dlnb, None
 
 
@@ -285,23 +282,12 @@ class _LayerGrads:
             off += p
 
 
-# Measured on MI355X (profiles/r2_overlap_experiments.md): every contraction launch fills all 256 CUs with one 128-KiB-LDS
-# workgroup each, so a second queue only interleaves whole workgroups -- 124.23 vs 124.25 ms per step.  Off by default.
-_DW_OVERLAP = os.environ.get("VIPANT_DW_STREAM", "0") == "1"
-_dw_streams: Dict[int, torch.cuda.Stream] = {}
-
-
-def _dw_stream(device) -> torch.cuda.Stream:
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _dw_streams:
-        _dw_streams[idx] = torch.cuda.Stream(device=device)
-    return _dw_streams[idx]
-
-
 class BackboneFn(torch.autograd.Function):
     """TransformerBackbone.forward = L x ResidualAttentionBlock (cvap/module/val.py:493-522) on the fp32
     residual stream x [batch*S, D].  One autograd node for the whole stack: the layer loop, the saved
-    activations and the (fp32, bf16) gradient-stream pair between layers are managed here, not by autograd."""
+    activations and the (fp32, bf16) gradient-stream pair between layers are managed here, not by autograd.
+    Per block four entry points of the fused operator set each way (include/vipant_hip.h): vipant_ln_qkv_*, vipant_mha_*,
+    vipant_gemm_bias_residual_*, vipant_ln_mlp_quickgelu_*."""
 
     @staticmethod
     def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, *params):
@@ -311,19 +297,23 @@ class BackboneFn(torch.autograd.Function):
         L, H = len(params) // 12, D // 64
         train = any(ctx.needs_input_grad)
         dev = x.device
+        st = _stream()
         saved: List[torch.Tensor] = []
         wts: List[Tuple[torch.Tensor, ...]] = []
         x = x.contiguous()
+
+        def new(cols, dtype=BF16):
+            return torch.empty((M, cols), dtype=dtype, device=dev)
         # Per block (cvap/module/val.py:519-522):  x1 = x + attn(ln_1(x));  x2 = x1 + mlp(ln_2(x1)).
         # The branch outputs y1, y2 leave their contraction as bf16 and the residual add is fused into the NEXT
         # LayerNorm pass (fp32 stream in, fp32 stream + bf16 normalised activations out), so every contraction has a
         # plain single-output bf16 epilogue and the fp32 stream is only touched by the streaming LN kernels.
+        keep_mlp = train and not recompute_mlp
         if not train:   # frozen tower: one set of temporaries for all layers
-            qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
-            u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-            g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-            y1 = torch.empty((M, D), dtype=BF16, device=dev)
-            y2 = torch.empty((M, D), dtype=BF16, device=dev)
+            h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
+            mean = torch.empty((M,), dtype=F32, device=dev); rstd = torch.empty((M,), dtype=F32, device=dev)
+        if not keep_mlp:
+            u, g = new(4 * D), new(4 * D)
         y_prev = None
         for l in range(L):
             ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
@@ -331,27 +321,35 @@ class BackboneFn(torch.autograd.Function):
                 wqkv_b, wqkv_t = cast_bf16(wqkv, True); wo_b, wo_t = cast_bf16(wo, True)
                 wfc_b, wfc_t = cast_bf16(wfc, True); wpr_b, wpr_t = cast_bf16(wpr, True)
                 wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None))
-                qkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
-                u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-                g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-                y1 = torch.empty((M, D), dtype=BF16, device=dev)
-                y2 = torch.empty((M, D), dtype=BF16, device=dev)
+                h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
+                mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
+                if keep_mlp:
+                    u, g = new(4 * D), new(4 * D)
             else:
                 wqkv_b, wo_b, wfc_b, wpr_b = (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
-            if y_prev is None:
-                h1, _, mean1, rstd1 = layernorm_fwd(x, ln1w, ln1b)
-            else:       # x <- x1_prev + y2_prev, fused with ln_1 of this block
-                h1, _, mean1, rstd1, x = layernorm_fwd(x, ln1w, ln1b, add=y_prev, want_sum=True)
-            gemm_nt(h1, wqkv_b, qkv, bias=bqkv, epi=EPI_BF16)
+                mean1 = mean2 = mean; rstd1 = rstd2 = rstd
+            # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
+            xs = new(D, F32) if y_prev is not None else None
+            call("vipant_ln_qkv_fwd", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
+                 bqkv.data_ptr(), h1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D, st)
+            if xs is not None:
+                x = xs
             o, lse = mha_fwd(qkv, batch, S, H, causal)
-            gemm_nt(o, wo_b, y1, bias=bo, epi=EPI_BF16)
-            h2, _, mean2, rstd2, x1 = layernorm_fwd(x, ln2w, ln2b, add=y1, want_sum=True)
-            gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
-            gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
+            call("vipant_gemm_bias_residual_fwd", o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(), M, D, D, st)
+            # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
+            x1 = new(D, F32)
+            if "gemm_nt" in KERNEL_PROBE:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
+                h2, _, mean2, rstd2, x1 = layernorm_fwd(x, ln2w, ln2b, add=y1, want_sum=True)
+                gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
+                gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
+            else:
+                call("vipant_ln_mlp_quickgelu_fwd", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
+                     wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
+                     rstd2.data_ptr(), u.data_ptr(), g.data_ptr(), y2.data_ptr(), M, D, st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
-                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2] + ([] if recompute_mlp else [u, g])
+                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2] + ([u, g] if keep_mlp else [])
             x, y_prev = x1, y2
         x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
@@ -368,81 +366,53 @@ class BackboneFn(torch.autograd.Function):
         ns = 11 if recompute_mlp else 13
         saved, params = tensors[:ns * L], tensors[ns * L:]
         dev = dx_in.device
-        dx = dx_in.contiguous()
-        M, D = dx.shape
+        st = _stream()
+        M, D = dx_in.shape
+        # gradient of the residual stream: fp32 master + bf16 copy (the operand of the next contraction), both updated in place
+        dx = dx_in.contiguous().clone()
         dx_b = cast_bf16_flat(dx)
+        ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
+        du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
+        dh = torch.empty((M, D), dtype=BF16, device=dev)
+        do = torch.empty((M, D), dtype=BF16, device=dev)
+        if recompute_mlp:
+            u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
         grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
         lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
         colsum(dx_b, lg.views[11])          # d c_proj.bias of the top block; lower blocks get theirs from ln_1's backward
-        # The four weight-gradient contractions of a block feed nothing in the dX chain: they run on a side stream, ordered
-        # behind their operands only, so their workgroups fill in beside the HBM-bound LayerNorm / attention kernels and the
-        # short last rounds of the dX contractions on the main stream (the reference's autograd runs all of it in series:
-        # cvap/monitor/cvalp.py:203).
-        main = torch.cuda.current_stream(dev)
-        side = _dw_stream(dev) if _DW_OVERLAP else None
-
-        def dweight(a, b, c, a_colsum=None):
-            if side is None:
-                gemm_tn(a, b, c, a_colsum=a_colsum)
-                return
-            side.wait_stream(main)                      # operands are complete on the main stream
-            with torch.cuda.stream(side):
-                gemm_tn(a, b, c, a_colsum=a_colsum, ws_name="gemm_tn_side")
-            a.record_stream(side); b.record_stream(side)        # not handed to another tensor while the side stream reads
-
         for l in reversed(range(L)):
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             ln1w, _, _, _, _, _, ln2w, _, _, bfc, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
             wqkv_t, wo_t, wfc_t, wpr_t, wfc_b = ctx.wts[l]
-            if recompute_mlp:
-                u = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-                g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-                gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU)
-            else:
-                u, g = saved[ns * l + 11:ns * l + 13]
             (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
             lg_below = _LayerGrads([p.shape for p in params[12 * (l - 1):12 * l]], dev) if l > 0 else None
-            # c_proj + QuickGELU'
-            du = torch.empty((M, 4 * D), dtype=BF16, device=dev)
-            gemm_nt(dx_b, wpr_t, du, aux=u, epi=EPI_DQUICKGELU)
-            dweight(dx_b, g, d_wpr)
             if recompute_mlp:
-                del u, g
-            # c_fc
-            dh2 = torch.empty((M, D), dtype=BF16, device=dev)
-            gemm_nt(du, wfc_t, dh2, epi=EPI_BF16)
-            dweight(du, h2, d_wfc, a_colsum=d_bfc)
-            del du
-            # ln_2 (+ residual gradient); its output dx1 is also d(out_proj output): column sum = d out_proj.bias
-            dx1 = torch.empty((M, D), dtype=F32, device=dev)
-            dx1_b = torch.empty((M, D), dtype=BF16, device=dev)
-            layernorm_bwd(dh2, x1, mean2, rstd2, ln2w, dres=dx, dx=dx1, dx_bf16=dx1_b, dgamma=d_ln2w, dbeta=d_ln2b,
-                          dx_colsum=d_bo)
-            # out_proj
-            do = dh2
-            gemm_nt(dx1_b, wo_t, do, epi=EPI_BF16)
-            dweight(dx1_b, o, d_wo)
-            # attention core
-            dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
-            # in_proj
-            dh1 = do
-            gemm_nt(dqkv, wqkv_t, dh1, epi=EPI_BF16)
-            dweight(dqkv, h1, d_wqkv, a_colsum=d_bqkv)
-            del dqkv
-            # ln_1 (+ residual gradient): the fp32 stream gradient is updated in place; its bf16 copy goes to a fresh buffer
-            # when the side stream may still be reading the old one (d out_proj.weight above).  The produced dx is
+                call("vipant_mlp_quickgelu_recompute", h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(), g.data_ptr(),
+                     M, D, st)
+            else:
+                u, g = saved[ns * l + 11:ns * l + 13]
+            # MLP half: c_proj^T + QuickGELU', c_fc^T, both weight gradients, ln_2 backward (+ residual gradient);
+            # the produced stream gradient is also d(out_proj output): its column sum is d out_proj.bias
+            call("vipant_ln_mlp_quickgelu_bwd", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(), g.data_ptr(),
+                 h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), dx.data_ptr(), dx_b.data_ptr(),
+                 du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
+                 d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(), st)
+            # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
-            dxn_b = dx1_b if side is None else torch.empty((M, D), dtype=BF16, device=dev)
-            layernorm_bwd(dh1, x, mean1, rstd1, ln1w, dres=dx1, dx=dx1, dx_bf16=dxn_b, dgamma=d_ln1w, dbeta=d_ln1b,
-                          dx_colsum=lg_below.views[11] if lg_below is not None else None)
-            dx, dx_b = dx1, dxn_b
+            call("vipant_gemm_bias_residual_bwd", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
+                 M, D, D, ws.data_ptr(), ws.numel(), st)
+            dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
+            call("vipant_ln_qkv_bwd", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
+                 rstd1.data_ptr(), ln1w.data_ptr(), dx.data_ptr(), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
+                 d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
+                 lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(), st)
+            del dqkv
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
             if ctx.grad_sync is not None:
-                ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12], also_after=side)
+                ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
             lg = lg_below
-        if side is not None:
-            main.wait_stream(side)          # every weight gradient is complete before autograd hands them on
         ctx.wts = None
         need = ctx.needs_input_grad
         out_grads = [gr if need[6 + i] else None for i, gr in enumerate(grads)]
@@ -452,7 +422,7 @@ class BackboneFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------- read-out
 class ReadoutFn(torch.autograd.Function):
     """ViTPostEncoder / GPTPostEncoder (cvap/module/val.py:288-289, 143-145) + the optional L2 normalisation of
-    MetaHead.forward (clip_head.py:117-118): LN(x[b, idx_b]) @ proj -> [batch, E] fp32."""
+    MetaHead.forward (clip_head.py:117-118): LN(x[b, idx_b]) @ proj -> [batch, E] fp32 -- vipant_cls_ln_proj_l2norm_{fwd,bwd}."""
 
     @staticmethod
     def forward(ctx, x, idx, batch, S, ln_w, ln_b, proj, normalized):
@@ -461,57 +431,43 @@ class ReadoutFn(torch.autograd.Function):
         D, E = proj.shape
         dev = x.device
         train = any(ctx.needs_input_grad)
-        if idx is None:
-            rows, src, ld = batch, x, S * D                # cls row of every sample: strided view, no copy
-        else:
-            src = torch.empty((batch, D), dtype=F32, device=dev)
-            call("vipant_gather_rows", x.data_ptr(), idx.data_ptr(), src.data_ptr(), batch, S, D, _stream())
-            rows, ld = batch, D
-        y, _, mean, rstd = layernorm_fwd(src, ln_w.detach(), ln_b.detach(), rows=rows, ldx=ld)
+        rows = torch.empty((batch, D), dtype=F32, device=dev) if idx is not None else None
+        y = torch.empty((batch, D), dtype=BF16, device=dev)
+        mean = torch.empty((batch,), dtype=F32, device=dev)
+        rstd = torch.empty((batch,), dtype=F32, device=dev)
         if train:
             proj_b, proj_t = cast_bf16(proj.detach(), True)
         else:
             proj_b, proj_t = None, cached_bf16(proj, transpose_only=True)
         feat = torch.empty((batch, E), dtype=F32, device=dev)
-        gemm_nt(y, proj_t, feat, epi=EPI_F32)
-        norm = None
-        if normalized:
-            out = torch.empty_like(feat)
-            norm = torch.empty((batch,), dtype=F32, device=dev)
-            call("vipant_l2norm_fwd", feat.data_ptr(), out.data_ptr(), norm.data_ptr(), batch, E, _stream())
-        else:
-            out = feat
+        out = torch.empty_like(feat) if normalized else feat
+        norm = torch.empty((batch,), dtype=F32, device=dev) if normalized else None
+        call("vipant_eot_ln_proj_l2norm_fwd" if idx is not None else "vipant_cls_ln_proj_l2norm_fwd", x.data_ptr(), _ptr(idx),
+             ln_w.detach().data_ptr(), ln_b.detach().data_ptr(), proj_t.data_ptr(), _ptr(rows), y.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), feat.data_ptr(), out.data_ptr(), _ptr(norm), batch, S, D, E, int(bool(normalized)), _stream())
         if train:
-            ctx.save_for_backward(x, idx, src if idx is not None else None, y, mean, rstd, ln_w, proj_b, out, norm)
+            ctx.save_for_backward(x, idx, rows, y, mean, rstd, ln_w, proj_b, out, norm)
             ctx.meta = (batch, S, D, E, bool(normalized))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, idx, src, y, mean, rstd, ln_w, proj_b, out, norm = ctx.saved_tensors
+        x, idx, rows, y, mean, rstd, ln_w, proj_b, out, norm = ctx.saved_tensors
         batch, S, D, E, normalized = ctx.meta
         dev = dout.device
         dout = dout.contiguous()
-        df_b = torch.empty((batch, E), dtype=BF16, device=dev)
-        if normalized:
-            call("vipant_l2norm_bwd", dout.data_ptr(), out.data_ptr(), norm.data_ptr(), None, df_b.data_ptr(), batch, E,
-                 _stream())
-        else:
-            df_b = cast_bf16_flat(dout)
+        dfeat = torch.empty((batch, E), dtype=BF16, device=dev)
         dy = torch.empty((batch, D), dtype=BF16, device=dev)
-        gemm_nt(df_b, proj_b, dy, epi=EPI_BF16)               # dy = dfeat @ proj^T ; proj [D, E] is the [N, K] operand
+        drows = torch.empty((batch, D), dtype=F32, device=dev) if idx is not None else None
         dproj = torch.empty((D, E), dtype=F32, device=dev)
-        gemm_tn(y, df_b, dproj)
         dlnw = torch.empty((D,), dtype=F32, device=dev)
         dlnb = torch.empty((D,), dtype=F32, device=dev)
         dx = torch.zeros_like(x)
-        if idx is None:
-            layernorm_bwd(dy, x, mean, rstd, ln_w.detach(), dx=dx, lddx=S * D, dgamma=dlnw, dbeta=dlnb, rows=batch,
-                          ldx=S * D)
-        else:
-            dsrc = torch.empty((batch, D), dtype=F32, device=dev)
-            layernorm_bwd(dy, src, mean, rstd, ln_w.detach(), dx=dsrc, dgamma=dlnw, dbeta=dlnb)
-            call("vipant_scatter_rows", dsrc.data_ptr(), idx.data_ptr(), dx.data_ptr(), batch, S, D, _stream())
+        ws = scratch("readout_bwd", query("vipant_cls_ln_proj_l2norm_bwd_workspace_bytes", batch, D, E), dev)
+        call("vipant_cls_ln_proj_l2norm_bwd", dout.data_ptr(), out.data_ptr(), _ptr(norm), x.data_ptr(), _ptr(idx), _ptr(rows),
+             y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln_w.detach().data_ptr(), proj_b.data_ptr(), dfeat.data_ptr(),
+             dy.data_ptr(), _ptr(drows), dx.data_ptr(), dproj.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), batch, S, D, E,
+             int(normalized), ws.data_ptr(), ws.numel(), _stream())
         return dx, None, None, None, dlnw, dlnb, dproj, None
 
 
@@ -524,7 +480,7 @@ def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor):
     assert pos.shape[0] >= L
     x = torch.empty((b * L, D), dtype=F32, device=tokens.device)
     eot = torch.empty((b,), dtype=I64, device=tokens.device)
-    call("vipant_embed_tokens", tokens.data_ptr(), table.detach().data_ptr(), pos.detach().contiguous().data_ptr(),
+    call("vipant_embed_gather_pos_fwd", tokens.data_ptr(), table.detach().data_ptr(), pos.detach().contiguous().data_ptr(),
          x.data_ptr(), eot.data_ptr(), b, L, D, _stream())
     return x, eot
 

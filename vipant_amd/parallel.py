@@ -88,12 +88,11 @@ class GradSync:
             self.stream = torch.cuda.Stream(device=device)
         return self.stream
 
-    def reduce_async(self, flat: torch.Tensor, views=None, params=None, also_after=None):
+    def reduce_async(self, flat: torch.Tensor, views=None, params=None):
         """Start the SUM all-reduce of one bucket.  `views` / `params` (optional, same length) name the slices of
         `flat` that are the gradients of `params`: autograd usually CLONES a gradient it is handed while other
         references to it exist, so after the reduction `wait()` copies the reduced slices over whatever tensor ended
-        up in `param.grad`.  `also_after`: a second stream whose queued work also writes into the bucket (the weight-
-        gradient contractions of ops.BackboneFn)."""
+        up in `param.grad`."""
         if not active():
             return
         if views is not None:
@@ -101,8 +100,6 @@ class GradSync:
         if flat.is_cuda:
             comm = self._comm_stream(flat.device)
             comm.wait_stream(torch.cuda.current_stream(flat.device))    # bucket is complete on the compute stream
-            if also_after is not None:
-                comm.wait_stream(also_after)
             with torch.cuda.stream(comm):
                 self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             flat.record_stream(comm)
