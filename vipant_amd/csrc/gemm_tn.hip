@@ -8,6 +8,8 @@
 // (on the DMA source address and on the read address) so the 32 lanes of a half-wave hit all 64 banks.
 // 256x256 output tile per 512-thread workgroup; the M range is split over workgroups to fill 256 CUs and
 // the fp32 partial tiles are summed by a second deterministic pass (no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -199,6 +201,207 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong variant (same idea as gemm_nt_pp_kernel, see gemm_nt.hip): the two wave groups (wp = 0: output rows p0..p0+127,
+// wp = 1: p0+128..p0+255) run the same stream half a K-tile apart, so that one group's LDS-DMA issue burst overlaps the
+// other group's MFMAs on every SIMD.  A columns are private to a group (two [64 m][128 p] stages of 16 KiB each, filled by the
+// group one K-tile ahead); B is read by both groups and lives in a ring of three [64 m][256 q] slots (group 0 fills tile rows
+// 0-31 of slot k+1, group 1 rows 32-63 of slot k+2, each at the start of ITS K-tile k).  Waits before the barrier that ends
+// an interval -- group 0: none | vmcnt(0);  group 1: vmcnt(8) | vmcnt(4).  Every wave issues 8 DMA pieces per K-tile
+// unconditionally (past the split's range they read rows the loop never consumes, past the matrix the descriptor returns
+// zeros), so the counts are exact.
+constexpr int PP_A_STAGE = BK * 128 * 2;                 // 16 KiB
+constexpr int PP_B_BASE = 4 * PP_A_STAGE;                // [group][stage]
+constexpr int PP_B_SLOT = BK * TQ * 2;                   // 32 KiB
+constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wl = wave & 3;            // grp = wp, wl = wq
+
+    const int ntq = (p.Q + TQ - 1) / TQ, ntp = (p.P + TP - 1) / TP;
+    const int ntiles = ntp * ntq;
+    const int bid = xcd_remap(blockIdx.x, ntiles * p.splits);
+    const int split = bid / ntiles, tile = bid % ntiles;
+    const int tp = tile / ntq, tq = tile % ntq;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int nk_total = (p.M + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    int nk = nk_total - kt0;
+    if (nk > p.kt_per_split) nk = p.kt_per_split;
+    const int mbeg = kt0 * BK;
+
+    // descriptors: A based at this group's first column, B at the tile's first column; rows >= M read as zero
+    const bf16_t* Ab = p.A + (int64_t)mbeg * p.lda + p0 + grp * 128;
+    const bf16_t* Bb = p.B + (int64_t)mbeg * p.ldb + q0;
+    int64_t a_bytes = ((int64_t)(p.M - mbeg) * p.lda - p0 - grp * 128) * 2;
+    int64_t b_bytes = ((int64_t)(p.M - mbeg) * p.ldb - q0) * 2;
+    if (a_bytes < 0) a_bytes = 0;
+    if (b_bytes < 0) b_bytes = 0;
+    const auto rsA = make_rsrc(Ab, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
+    const auto rsB = make_rsrc(Bb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
+
+    // DMA.  A: one instruction = 4 tile rows x 256 B; wave wl of a group fills rows wl*16 .. wl*16+15 of the group's stage.
+    //       B: one instruction = 2 tile rows x 512 B; wave w fills rows w*8 .. w*8+7 of the slot (group 0: 0-31, group 1: 32-63).
+    uint32_t voffA[4], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ma = wl * 16 + i * 4 + (lane >> 4);
+        voffA[i] = (uint32_t)(ma * p.lda * 2 + (((lane & 15) ^ tn_swz(ma)) << 4));
+        const int mb = (wave * 4 + i) * 2 + (lane >> 5);
+        voffB[i] = (uint32_t)(mb * p.ldb * 2 + (((lane & 31) ^ tn_swz(mb)) << 4));
+    }
+    const uint32_t kstepA = (uint32_t)(BK * p.lda * 2), kstepB = (uint32_t)(BK * p.ldb * 2);
+    char* const ldsA = smem + grp * (2 * PP_A_STAGE) + wl * 4096;
+    char* const ldsB = smem + PP_B_BASE + wave * 4096;
+    auto fill_a = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsA, ldsA + stage * PP_A_STAGE + i * 1024, voffA[i], (uint32_t)kt * kstepA);
+    };
+    auto fill_b = [&](int slot, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsB, ldsB + slot * PP_B_SLOT + i * 1024, voffB[i], (uint32_t)kt * kstepB);
+    };
+
+    // transposed fragment reads (see gemm_tn_kernel): A rows are 256 B here, B rows 512 B
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    uint32_t rdA[2][2], rdB[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 8 * g + 4 * h + qq;
+            const uint32_t sw = (uint32_t)((((pp >> 1) ^ tn_swz(m)) << 4) + (pp & 1) * 8);
+            rdA[ks][h] = (uint32_t)(m * 256) + sw;
+            rdB[ks][h] = (uint32_t)(m * 512) + sw;
+        }
+    const uint32_t lds0 = lds_offset(smem);
+    const uint32_t baseA = lds0 + (uint32_t)(grp * (2 * PP_A_STAGE)), baseB = lds0 + (uint32_t)PP_B_BASE;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // column sums of A (bias gradient): each group sums its own 128 columns; the ntq workgroups sharing an A tile take turns
+    const bool do_colsum = p.colsum != nullptr;
+    const int tl = tid & 255;
+    const int cs_chunk = tl & 15, cs_rg = tl >> 4;
+    float cs_acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs_acc[e] = 0.f;
+
+    // 32 MFMAs of one k-step
+    auto half_ktile = [&](int ks, uint32_t tA, uint32_t tB) {
+        bf16x8 fq[4], fp[3];
+        auto fragA = [&](int cb) { return lds_read_tr16_pair_raw(tA + (rdA[ks][0] ^ (uint32_t)(cb << 5)), tA + (rdA[ks][1] ^ (uint32_t)(cb << 5))); };
+        auto fragB = [&](int cb) { return lds_read_tr16_pair_raw(tB + (rdB[ks][0] ^ (uint32_t)(cb << 5)), tB + (rdB[ks][1] ^ (uint32_t)(cb << 5))); };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fq[j] = fragB(wl * 4 + j);
+        fp[0] = fragA(0);
+        fp[1] = fragA(1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t + 2 < 8) fp[(t + 2) % 3] = fragA(t + 2);
+            if (t + 2 < 8) lds_raw_wait<4>(); else if (t + 1 < 8) lds_raw_wait<2>(); else lds_raw_wait<0>();
+            lds_raw_use(fp[t % 3]);
+            if (t == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds_raw_use(fq[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[j], fp[t % 3], acc[t][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: K-tile 0 (and, for group 1, its B rows of K-tile 1)
+    fill_a(0, 0);
+    fill_b(0, 0);
+    if (grp == 1) {
+        fill_b(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // the lag
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        const uint32_t tA = baseA + (uint32_t)(stage * PP_A_STAGE), tB = baseB + (uint32_t)(slot * PP_B_SLOT);
+        fill_a(stage ^ 1, kt + 1);
+        if (grp == 0) fill_b(slot1, kt + 1); else fill_b(slot2, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_colsum && (kt % ntq) == tq) {
+            const char* sA = smem + grp * (2 * PP_A_STAGE) + stage * PP_A_STAGE;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int m = cs_rg + 16 * k4;
+                const bf16x8 v = *(const bf16x8*)(sA + m * 256 + ((cs_chunk ^ tn_swz(m)) << 4));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs_acc[e] += (float)v[e];
+            }
+        }
+        half_ktile(0, tA, tB);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        half_ktile(1, tA, tB);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = slot1;
+    }
+    // the (unused) fills issued by the last K-tiles must have landed in this group's A stages before they are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // column-sum partials: the group's own (now idle) A stages serve as the reduction buffer
+    float* red = (float*)(smem + grp * (2 * PP_A_STAGE));        // [16 row groups][128 columns] fp32 = 8 KiB
+    if (do_colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[cs_rg * 128 + cs_chunk * 8 + e] = cs_acc[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
+    if (do_colsum && tl < 128) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += red[r * 128 + tl];
+        p.colsum[((int64_t)split * ntq + tq) * (ntp * TP) + p0 + grp * 128 + tl] = sum;
+    }
+    // lane holds C[p = p0 + grp*128 + i*16 + (lane&15)][q = q0 + wl*64 + j*16 + (lane>>4)*4 + 0..3]
+    const int frow = lane & 15;
+    if (p.direct) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = p0 + grp * 128 + i * 16 + frow;
+            if (pr >= p.P) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qc = q0 + wl * 64 + j * 16 + g * 4;
+                if (qc < p.Q) *(f32x4*)(p.out + (int64_t)pr * p.ldo + qc) = acc[i][j];
+            }
+        }
+    } else {
+        float* slab = p.out + ((int64_t)split * ntiles + tile) * (TP * TQ);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4*)(slab + (grp * 128 + i * 16 + frow) * TQ + wl * 64 + j * 16 + g * 4) = acc[i][j];
+    }
+}
+
 __global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, int P, int Q, int splits,
                                       int accumulate) {
     const int ntq = (Q + TQ - 1) / TQ, ntp = (P + TP - 1) / TP;
@@ -273,7 +476,7 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
                    "gemm_tn: operands must be 16-byte aligned");
     int splits, per;
     plan(M, P, Q, &splits, &per);
-    VIPANT_REQUIRE((int64_t)(per + 1) * BK * (lda > ldb ? lda : ldb) * 2 < (1ll << 32), VIPANT_EBADSHAPE,
+    VIPANT_REQUIRE((int64_t)(per + 3) * BK * (lda > ldb ? lda : ldb) * 2 < (1ll << 32), VIPANT_EBADSHAPE,
                    "gemm_tn: per-split byte range exceeds 4 GiB");
     const size_t need = vipant_gemm_tn_workspace_bytes(M, P, Q);
     const int direct = (splits == 1 && !accumulate) ? 1 : 0;
@@ -281,9 +484,13 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
         VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= need, VIPANT_ENOWORKSPACE,
                        "gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
     static bool configured = false;
+    static int variant = 0;
     if (!configured) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * STAGE_BYTES));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           PP_LDS_BYTES));
+        variant = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;     // bit 16: the two-stage kernel
         configured = true;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -292,7 +499,8 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     float* cs_part = a_colsum != nullptr ? (float*)((char*)workspace + slab_bytes) : nullptr;
     GemmTN p{(const bf16_t*)A, (const bf16_t*)B, direct ? C : (float*)workspace, lda, ldb, direct ? ldc : TQ,
              (int)M, (int)P, (int)Q, splits, per, direct, cs_part};
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 2 * STAGE_BYTES, s, p);
+    if (variant & 16) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 2 * STAGE_BYTES, s, p);
+    else hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(512), PP_LDS_BYTES, s, p);
     VIPANT_LAUNCH_CHECK();
     if (!direct) {
         const int64_t total4 = tiles * TP * TQ / 4;
