@@ -373,7 +373,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         offB[ks] = (uint32_t)(PP_B_BASE + (wl * 64 + frow) * 128) + cb;
     }
 
-    struct TileDesc { __amdgpu_buffer_rsrc_t a, b; int m0, n0; };
+    // a tile's operand panels as (base pointer, byte range): scalars, so that "this tile or the next one" is a scalar select and
+    // the buffer descriptor built from it stays in SGPRs (a select between two descriptors made hipcc keep them in VGPRs and
+    // wrap every LDS-DMA in a readfirstlane loop)
+    struct TileDesc { const bf16_t* a; const bf16_t* b; uint32_t abytes, bbytes; int m0, n0; };
     auto describe = [&](int tile) {
         TileDesc d;
         if (tile < ntiles) {
@@ -381,11 +384,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             d.m0 = tm * BM; d.n0 = tn * BN;
             const int64_t a_bytes = ((int64_t)(p.M - d.m0) * p.lda - (p.lda - p.K)) * 2;
             const int64_t b_bytes = ((int64_t)(p.N - d.n0) * p.ldb - (p.ldb - p.K)) * 2;
-            d.a = make_rsrc(p.A + (int64_t)d.m0 * p.lda, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
-            d.b = make_rsrc(p.B + (int64_t)d.n0 * p.ldb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
+            d.a = p.A + (int64_t)d.m0 * p.lda; d.abytes = (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes);
+            d.b = p.B + (int64_t)d.n0 * p.ldb; d.bbytes = (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes);
         } else {                                   // past the last tile: zero records, every lane out of range, no traffic
             d.m0 = p.M; d.n0 = 0;
-            d.a = make_rsrc(p.A, 0); d.b = make_rsrc(p.B, 0);
+            d.a = p.A; d.b = p.B; d.abytes = 0; d.bbytes = 0;
         }
         return d;
     };
@@ -435,11 +438,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     TileDesc cur = describe(tile), nxt = describe(tile + G);
     int gk = 0, slot = 0;                       // K-tile counter of the stream: A stage = gk & 1, B slot = gk % 3
     // prologue: K-tile 0 of the first tile (and, for group 1, its B rows of K-tile 1)
-    fill_a(cur.a, 0, 0);
-    fill_b(cur.b, 0, 0);
+    fill_a(make_rsrc(cur.a, cur.abytes), 0, 0);
+    fill_b(make_rsrc(cur.b, cur.bbytes), 0, 0);
     if (grp == 1) {
         const bool wrap = nk < 2;
-        fill_b(wrap ? nxt.b : cur.b, 1, wrap ? 0u : (uint32_t)(BK * 2));
+        fill_b(wrap ? make_rsrc(nxt.b, nxt.bbytes) : make_rsrc(cur.b, cur.bbytes), 1, wrap ? 0u : (uint32_t)(BK * 2));
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,8 +466,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             }
             {   // first interval: DMA of the stream's next K-tile(s), k-step 0
                 const bool w1 = k + 1 >= nk, w2 = k + 2 >= nk;
-                const __amdgpu_buffer_rsrc_t& ra = w1 ? nxt.a : cur.a;
-                const __amdgpu_buffer_rsrc_t& rb = grp == 0 ? (w1 ? nxt.b : cur.b) : (w2 ? nxt.b : cur.b);
+                const bool wb = grp == 0 ? w1 : w2;
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(w1 ? nxt.a : cur.a, w1 ? nxt.abytes : cur.abytes);
+                const __amdgpu_buffer_rsrc_t rb = make_rsrc(wb ? nxt.b : cur.b, wb ? nxt.bbytes : cur.bbytes);
                 const uint32_t ka = w1 ? 0u : (uint32_t)((k + 1) * BK * 2);
                 const uint32_t kb = grp == 0 ? ka : (uint32_t)((w2 ? k + 2 - nk : k + 2) * BK * 2);
                 char* const da = ldsA + (stage ^ 1) * PP_A_STAGE;
@@ -478,6 +482,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dma_piece(i);
+                } else if (VAR == 3) {             // spread: one piece behind each MFMA group of k-step 0
+                    frag_head(0, stage, slot);
                 } else {                           // burst at the top of the K-tile
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dma_piece(i);
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     frag_head(0, stage, slot);
                 }
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                if (VAR == 3) half_body(0, stage, dma_piece); else
                 half_body(0, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -594,6 +601,7 @@ template <int EPI>
 int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     if (p.dbg & 32) return launch_pp_variant<EPI, 1>(p, stream);
     if (p.dbg & 64) return launch_pp_variant<EPI, 2>(p, stream);
+    if (p.dbg & 128) return launch_pp_variant<EPI, 3>(p, stream);
     return launch_pp_variant<EPI, 0>(p, stream);
 }
 

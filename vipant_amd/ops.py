@@ -586,24 +586,42 @@ class InfoNCEFn(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------- LARS
 class LarsState:
-    """Device-side pointer tables for vipant_lars_step (cvap/module/lars.py:43-72); built once per optimizer."""
+    """Device-side pointer tables for vipant_lars_step (cvap/module/lars.py:43-72); built once per optimizer.
+
+    The per-step inputs -- gradient pointers and learning rates -- reach the device through two alternating PINNED host
+    buffers and stream-ordered copies: the host never waits for the stream here (a `torch.tensor(list, device=...)` per step
+    is a pageable copy, i.e. a stream synchronisation in the middle of the training loop)."""
 
     def __init__(self, params: Sequence[torch.Tensor], adapt: Sequence[bool]):
         self.params = list(params)
         dev = self.params[0].device
+        n = len(self.params)
         self.mu = [torch.zeros_like(p) for p in self.params]
         self.n = torch.tensor([p.numel() for p in self.params], dtype=I64, device=dev)
         self.adapt = torch.tensor([int(a) for a in adapt], dtype=torch.int32, device=dev)
         self.p_ptrs = torch.tensor([p.data_ptr() for p in self.params], dtype=I64, device=dev)
         self.mu_ptrs = torch.tensor([m.data_ptr() for m in self.mu], dtype=I64, device=dev)
-        self.ws = torch.empty((query("vipant_lars_workspace_bytes", len(self.params)),), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty((query("vipant_lars_workspace_bytes", n),), dtype=torch.uint8, device=dev)
+        self.g_ptrs = torch.empty((n,), dtype=I64, device=dev)
+        self.lr = torch.empty((n,), dtype=F32, device=dev)
+        self._host = [(torch.empty((n,), dtype=I64).pin_memory(), torch.empty((n,), dtype=F32).pin_memory(), None)
+                      for _ in range(2)] if dev.type == "cuda" else None
+        self._turn = 0
 
     def step(self, grads: Sequence[torch.Tensor], lrs: Sequence[float], weight_decay: float, momentum: float, eta: float):
-        dev = self.params[0].device
         for p, g in zip(self.params, grads):
             assert g.is_contiguous() and g.dtype == F32 and g.shape == p.shape
-        g_ptrs = torch.tensor([g.data_ptr() for g in grads], dtype=I64, device=dev)
-        lr = torch.tensor(list(lrs), dtype=F32, device=dev)
-        call("vipant_lars_step", self.p_ptrs.data_ptr(), g_ptrs.data_ptr(), self.mu_ptrs.data_ptr(), self.n.data_ptr(),
-             self.adapt.data_ptr(), lr.data_ptr(), len(self.params), float(weight_decay), float(momentum), float(eta),
+        hp, hl, ev = self._host[self._turn]
+        if ev is not None:
+            ev.synchronize()             # the copy issued from this buffer two steps ago (long done)
+        hp.copy_(torch.tensor([g.data_ptr() for g in grads], dtype=I64))
+        hl.copy_(torch.tensor(list(lrs), dtype=F32))
+        self.g_ptrs.copy_(hp, non_blocking=True)
+        self.lr.copy_(hl, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._host[self._turn] = (hp, hl, ev)
+        self._turn ^= 1
+        call("vipant_lars_step", self.p_ptrs.data_ptr(), self.g_ptrs.data_ptr(), self.mu_ptrs.data_ptr(), self.n.data_ptr(),
+             self.adapt.data_ptr(), self.lr.data_ptr(), len(self.params), float(weight_decay), float(momentum), float(eta),
              self.ws.data_ptr(), self.ws.numel(), _stream())
