@@ -78,13 +78,16 @@ int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, co
                              float* sum_out, void* stream);
 /* out fp32 [M, D] = x fp32 + add bf16 (the last block's residual add, no norm behind it). */
 int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int64_t n, void* stream);
-/* dx_f32[M,D] = dres (optional fp32 residual-stream gradient, may alias dx) + LN'(dy); dx_bf16 optional.
- * dy is bf16 [M,D] when dy_is_f32 == 0, fp32 otherwise.  dgamma / dbeta fp32 [D] (+)= column reductions;
+/* dx[M,D] = dres (optional residual-stream gradient) + LN'(dy); outputs dx_f32 (optional) and dx_bf16 (optional).
+ * flags: VIPANT_LN_DY_F32 -- dy is fp32 [M,D] (else bf16); VIPANT_LN_DRES_BF16 -- dres is bf16 [M,D] (row stride D; may be the
+ * same buffer as dx_bf16), else fp32 with row stride lddx (may alias dx_f32).  dgamma / dbeta fp32 [D] (+)= column reductions;
  * dx_colsum (optional fp32 [D]) (+)= sum over rows of the produced dx: the bias gradient of the Linear whose
  * output gradient this dx is (out_proj / c_proj), for free in the same pass. */
 size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
-int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx, const float* mean,
-                             const float* rstd, const float* gamma, const float* dres, float* dx_f32, int64_t lddx,
+#define VIPANT_LN_DY_F32 1
+#define VIPANT_LN_DRES_BF16 2
+int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx, const float* mean,
+                             const float* rstd, const float* gamma, const void* dres, float* dx_f32, int64_t lddx,
                              uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t accumulate,
                              int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -102,6 +105,8 @@ int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t*
 /* ---- elementwise / layout helpers ------------------------------------------------------------------
  * fp32 -> bf16 cast of a [R, C] matrix; dst_t (optional) receives the transpose [C, R]. */
 int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t R, int64_t C, void* stream);
+/* bf16 -> fp32 widening of n elements (n % 4 == 0). */
+int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
 /* conv1.weight [O, Cin, kh, kw] fp32 -> effective GEMM weight bf16 [O, Cout*kh*kw]; mean_channels != 0
  * averages the Cin stored channels into one (cvap/module/val.py:236-244), else Cout = Cin. */
 int32_t vipant_conv_weight_prep(const float* w, uint16_t* out, int64_t O, int64_t Cin, int64_t khw,
@@ -197,7 +202,9 @@ int32_t vipant_ln_qkv_fwd(const float* x, const uint16_t* add, float* x_out, con
                           const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd, uint16_t* qkv,
                           int64_t M, int64_t D, void* stream);
 /* dstream fp32 [M,D]: in = gradient of the residual stream after this block's attention branch, out = gradient before the block
- * (in place); dx_bf16 its bf16 copy; dh bf16 [M,D] scratch; dw fp32 [3D,D], db fp32 [3D], dgamma / dbeta fp32 [D];
+ * (in place); dx_bf16 its bf16 copy.  dstream == NULL: the gradient stream is kept in bf16 only -- dx_bf16 is read as the incoming
+ * gradient and overwritten with the outgoing one (the forward stream stays fp32; profiles/r2_stream_precision.md, model D).
+ * dh bf16 [M,D] scratch; dw fp32 [3D,D], db fp32 [3D], dgamma / dbeta fp32 [D];
  * dx_colsum (optional fp32 [D]) = column sums of the produced gradient (= d c_proj.bias of the block below). */
 int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x, const float* mean,
                           const float* rstd, const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* dh, float* dw,

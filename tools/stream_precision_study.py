@@ -9,6 +9,8 @@ functions (oracle/ref_cpu.py) with rounding points inserted:
   C  B + bf16 residual stream                 -- x <- bf16(x + branch) after every residual add, and the gradient stream
                                                  rounded to bf16 at the same points (what the reference's fp16 autocast does
                                                  with 3 more mantissa bits: clip/model.py:157-160, cvap/module/val.py:253-257)
+  D  B + bf16 GRADIENT stream only            -- forward as B (loss and features unchanged); the gradient of the residual
+                                                 stream is rounded to bf16 after every residual-gradient add
 Usage: python tools/stream_precision_study.py [b] [T] [F] [layers]
 Results are recorded in profiles/r2_stream_precision.md.
 """
@@ -36,7 +38,19 @@ class _Round(torch.autograd.Function):
         return (g.bfloat16().float() if ctx.bwd else g), None
 
 
+class _RoundBwd(torch.autograd.Function):       # forward untouched, gradient rounded to bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 def rnd(x, on=True, bwd=True):
+    if on == "grad":
+        return _RoundBwd.apply(x)
     return _Round.apply(x, bwd) if on else x
 
 
@@ -83,7 +97,8 @@ def main():
     aud = gen.det_randn("study/aud", (b, 1, T, Fq))
     img = R.l2_normalize(gen.det_randn("study/img", (b, 512)))
     out = {}
-    for name, q, qs in (("A fp32", False, False), ("B bf16 operands, fp32 stream", True, False), ("C bf16 operands, bf16 stream", True, True)):
+    for name, q, qs in (("A fp32", False, False), ("B bf16 operands, fp32 stream", True, False), ("C bf16 operands, bf16 stream", True, True),
+                        ("D bf16 operands, fp32 stream, bf16 GRADIENT stream", True, "grad")):
         sd = {k: v.clone().requires_grad_() for k, v in w.items()}
         ls = torch.tensor(2.6592600, requires_grad=True)
         feat = tower(aud, sd, L, stride, pr, q, qs)

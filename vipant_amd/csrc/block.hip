@@ -52,7 +52,10 @@ extern "C" int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv
     TRY(vipant_gemm_nt(dqkv, 3 * D, w_qkv_t, 3 * D, dh, D, nullptr, nullptr, 1.0f, M, D, 3 * D, VIPANT_EPI_BF16, stream));
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
     TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
-    // ln_1 backward + residual-gradient add, in place on the stream gradient
+    // ln_1 backward + residual-gradient add, in place on the stream gradient (fp32 master + bf16 copy, or bf16 only)
+    if (dstream == nullptr)
+        return vipant_layernorm_bwd(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma, dbeta,
+                                    dx_colsum, 0, M, D, workspace, workspace_bytes, stream);
     return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
                                 D, workspace, workspace_bytes, stream);
 }
@@ -114,6 +117,9 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_
     TRY(vipant_gemm_nt(du, 4 * D, w_fc_t, 4 * D, dh, D, nullptr, nullptr, 1.0f, M, D, 4 * D, VIPANT_EPI_BF16, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
+    if (dstream == nullptr)
+        return vipant_layernorm_bwd(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma, dbeta,
+                                    dx_colsum, 0, M, D, workspace, workspace_bytes, stream);
     return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
                                 D, workspace, workspace_bytes, stream);
 }

@@ -255,7 +255,24 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nc
     out[i] = accumulate ? out[i] + s : s;
 }
 
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const bf16x4 v = *(const bf16x4*)(src + i * 4);
+        *(f32x4*)(dst + i * 4) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream) {
+    VIPANT_REQUIRE(n > 0 && n % 4 == 0, VIPANT_EBADSHAPE, "cast_f32: n must be a positive multiple of 4 (n=%ld)", (long)n);
+    VIPANT_REQUIRE((uintptr_t)src % 8 == 0 && (uintptr_t)dst % 16 == 0, VIPANT_EALIGN, "cast_f32: misaligned");
+    int64_t blocks = ceil_div(n / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n / 4);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
 
 extern "C" int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t R, int64_t C, void* stream) {
     VIPANT_REQUIRE(R > 0 && C > 0, VIPANT_EBADSHAPE, "cast_bf16: empty");

@@ -59,12 +59,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd.
 // Per-block partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to `partial` [grid, 2, D].
-template <int NV, bool DY_F32>
+// DRES_BF16: the residual-stream gradient is a bf16 [M, D] tensor (read here, may be the same buffer as dxb: a lane reads its
+// elements of a row before it writes them) instead of an fp32 one.
+template <int NV, bool DY_F32, bool DRES_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     const float* dres, float* dx, int64_t lddx,
-                                                     bf16_t* __restrict__ dxb, float* __restrict__ partial, int64_t M) {
+                                                     const void* dres_, float* dx, int64_t lddx,
+                                                     bf16_t* dxb, float* __restrict__ partial, int64_t M) {
+    const float* dres = DRES_BF16 ? nullptr : (const float*)dres_;
+    const bf16_t* dresb = DRES_BF16 ? (const bf16_t*)dres_ : nullptr;
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
@@ -104,7 +108,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int t = 0; t < NV; ++t) {
             const int col = (t * 64 + lane) * 4;
             f32x4 o = (g[t] - s1 - xh[t] * s2) * rs;
-            if (dres != nullptr) o += *(const f32x4*)(dres + row * lddx + col);
+            if (DRES_BF16) {
+                const bf16x4 rb = *(const bf16x4*)(dresb + row * D + col);
+                o += f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
+            } else if (dres != nullptr) {
+                o += *(const f32x4*)(dres + row * lddx + col);
+            }
             dsum[t] += o;
             if (dx != nullptr) *(f32x4*)(dx + row * lddx + col) = o;
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
@@ -180,8 +189,8 @@ extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
     return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
-extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int64_t ldx,
-                                        const float* mean, const float* rstd, const float* gamma, const float* dres,
+extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx,
+                                        const float* mean, const float* rstd, const float* gamma, const void* dres,
                                         float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
                                         float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
                                         size_t workspace_bytes, void* stream) {
@@ -193,13 +202,19 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t dy_is_f32, const
     hipStream_t s = (hipStream_t)stream;
     const int blocks = ln_blocks(M);
     float* partial = (float*)workspace;
+    const bool dy_is_f32 = (flags & VIPANT_LN_DY_F32) != 0, dres_bf16 = (flags & VIPANT_LN_DRES_BF16) != 0;
+    VIPANT_REQUIRE(!(dres_bf16 && (dres == nullptr || dy_is_f32)), VIPANT_EBADSHAPE,
+                   "layernorm_bwd: a bf16 residual gradient needs dres and a bf16 dy");
 #define LN_BWD(NV)                                                                                                   \
     do {                                                                                                             \
         if (dy_is_f32)                                                                                               \
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd,     \
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, true, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+        else if (dres_bf16)                                                                                          \
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
                                gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
         else                                                                                                         \
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd,    \
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, false, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
                                gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
     } while (0)
     switch (D / 256) {

@@ -9,6 +9,7 @@ The residual stream and its gradient are fp32; every MFMA operand is bf16 (fp32 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -282,6 +283,9 @@ class _LayerGrads:
             off += p
 
 
+_GRAD_STREAM_F32 = os.environ.get("VIPANT_GRAD_STREAM", "bf16") == "fp32"
+
+
 class BackboneFn(torch.autograd.Function):
     """TransformerBackbone.forward = L x ResidualAttentionBlock (cvap/module/val.py:493-522) on the fp32
     residual stream x [batch*S, D].  One autograd node for the whole stack: the layer loop, the saved
@@ -369,9 +373,16 @@ class BackboneFn(torch.autograd.Function):
         dev = dx_in.device
         st = _stream()
         M, D = dx_in.shape
-        # gradient of the residual stream: fp32 master + bf16 copy (the operand of the next contraction), both updated in place
-        dx = dx_in.contiguous().clone()
-        dx_b = cast_bf16_flat(dx)
+        # Gradient of the residual stream.  Default: bf16 only -- the tensor the next contraction reads IS the stream (LayerNorm
+        # backward 10 instead of 16 B per element); the forward stream stays fp32, so the loss and the features are untouched and
+        # the gradients move from ~1.3 % to ~1.6 % rel-L2 of the fp32 reference (profiles/r2_stream_precision.md, model D; the
+        # reference's own GPU path keeps this stream in fp16).  VIPANT_GRAD_STREAM=fp32: fp32 master + bf16 copy, both in place.
+        if _GRAD_STREAM_F32:
+            dx = dx_in.contiguous().clone()
+            dx_b = cast_bf16_flat(dx)
+        else:
+            dx = None
+            dx_b = cast_bf16_flat(dx_in.contiguous())
         ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
         du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
         dh = torch.empty((M, D), dtype=BF16, device=dev)
@@ -396,7 +407,7 @@ class BackboneFn(torch.autograd.Function):
             # MLP half: c_proj^T + QuickGELU', c_fc^T, both weight gradients, ln_2 backward (+ residual gradient);
             # the produced stream gradient is also d(out_proj output): its column sum is d out_proj.bias
             call("vipant_ln_mlp_quickgelu_bwd", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(), g.data_ptr(),
-                 h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), dx.data_ptr(), dx_b.data_ptr(),
+                 h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(), st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
@@ -405,7 +416,7 @@ class BackboneFn(torch.autograd.Function):
                  M, D, D, ws.data_ptr(), ws.numel(), st)
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
             call("vipant_ln_qkv_bwd", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
-                 rstd1.data_ptr(), ln1w.data_ptr(), dx.data_ptr(), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
+                 rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(), st)
             del dqkv
@@ -416,6 +427,9 @@ class BackboneFn(torch.autograd.Function):
             lg = lg_below
         ctx.wts = None
         need = ctx.needs_input_grad
+        if dx is None and need[0]:
+            dx = torch.empty((M, D), dtype=F32, device=dev)
+            call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
         out_grads = [gr if need[6 + i] else None for i, gr in enumerate(grads)]
         return (dx if need[0] else None, None, None, None, None, None, *out_grads)
 
