@@ -231,6 +231,12 @@ def test_end_to_end_golden(M, golden, tag, L, b, T, Fq):
     gn = np.array([float(grads[k].norm()) for k in keys])
     ratio = gn / g["gnorm"]
     assert np.all(np.abs(ratio - 1) < 5e-2), (keys[int(np.abs(ratio - 1).argmax())], ratio.min(), ratio.max())
+    observe(f"e2e_{tag}_grads", gnorm_ratio_max_dev=float(np.abs(ratio - 1).max()),
+            cls=rel_l2(grads["misc.class_embedding"], g["g_cls"]), pos=rel_l2(grads["misc.positional_embedding"], g["g_pos"]),
+            proj=rel_l2(grads["post_encoder.proj"][::7, ::5], g["g_proj_slice"]),
+            conv=rel_l2(grads["pre_encoder.conv1.weight"][::61, :, ::5, ::7], g["g_conv_slice"]),
+            qkv_bias0=rel_l2(grads["encoder.resblocks.0.attn.in_proj_bias"], g["g_b0_qkv_bias"]),
+            fc_bias_last=rel_l2(grads[f"encoder.resblocks.{L - 1}.mlp.c_fc.bias"], g["g_last_fc_bias"]))
     assert rel_l2(grads["misc.class_embedding"], g["g_cls"]) < 5e-2
     assert rel_l2(grads["misc.positional_embedding"], g["g_pos"]) < 5e-2
     assert rel_l2(grads["post_encoder.proj"][::7, ::5], g["g_proj_slice"]) < 5e-2
