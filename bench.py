@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 D, L, E, HEADS = 768, 12, 512, 12
-DOMINANT_KERNEL = "gemm_nt_pp_kernel<3, 0>"       # c_fc forward + QuickGELU (name as rocprofv3 prints it)
+DOMINANT_KERNEL = "gemm_nt_pp_kernel<6, 0>"       # c_fc forward + QuickGELU, 8-bit QuickGELU' code (name as rocprofv3 prints it)
 
 
 def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
@@ -286,11 +286,11 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
-    # live per-launch timing of the dominant kernel: c_fc forward contraction (EPI_QUICKGELU), M = b*S, N = 4D, K = D
+    # live per-launch timing of the dominant kernel: c_fc forward contraction (EPI_QUICKGELU_D8), M = b*S, N = 4D, K = D
     S = mon.model.audio_head.misc.positional_embedding.shape[0]
     Mrows = b * S
     W = args.width
-    ops.KERNEL_PROBE["gemm_nt"] = {"events": [], "match": lambda epi, M, N, K: epi == ops.EPI_QUICKGELU and M == Mrows}
+    ops.KERNEL_PROBE["gemm_nt"] = {"events": [], "match": lambda epi, M, N, K: epi == ops.EPI_QUICKGELU_D8 and M == Mrows}
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -327,7 +327,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "%s (c_fc forward + QuickGELU, M=%d N=%d K=%d)" % (DOMINANT_KERNEL, Mrows, 4 * W, W),
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * W, W), "traffic_source": PMC_FILE,
-                     "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * W + 4 * W * W + 2 * Mrows * 4 * W),
+                     "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * W + 4 * W * W) + 3.0 * Mrows * 4 * W,
                      "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
     }
     if rank == 0:

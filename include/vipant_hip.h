@@ -38,6 +38,8 @@ extern "C" {
 #define VIPANT_EPI_QUICKGELU 3     /* U_bf16 = acc + bias ; C_bf16 = U * sigmoid(1.702 U)  (c_fc) */
 #define VIPANT_EPI_DQUICKGELU 4    /* C_bf16 = acc * dQuickGELU(U_bf16)        (backward of c_fc act) */
 #define VIPANT_EPI_SCALE_F32 5     /* C_f32  = alpha * acc */
+#define VIPANT_EPI_QUICKGELU_D8 6  /* as QUICKGELU, but aux receives uint8 codes of QuickGELU'(U) instead of U (1 B / element) */
+#define VIPANT_EPI_DQUICKGELU_D8 7 /* C_bf16 = acc * decode(aux uint8): backward of c_fc act from the 8-bit derivative code */
 
 const char* vipant_last_error(void);
 int32_t vipant_version(void);
@@ -48,7 +50,8 @@ int32_t vipant_device_check(void);
  *      cvap/module/val.py:500-506, 245-247, 288-289) ------------------------------------------------
  * C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous, bf16; fp32 accumulate on MFMA).
  * K % 64 == 0, N % 4 == 0.  bias (fp32 [N]) may be NULL.  `aux` is R (EPI_RESIDUAL_F32, may alias C),
- * U out (EPI_QUICKGELU) or U in (EPI_DQUICKGELU).  ldc applies to C and aux. */
+ * U out (EPI_QUICKGELU) or U in (EPI_DQUICKGELU), or the uint8 [M, N] matrix of QuickGELU' codes (the _D8 epilogues: the backward
+ * needs only the derivative, code = round((QuickGELU'(U) + 0.1) * 212.5), error <= 2.4e-3).  ldc applies to C and aux (elements). */
 int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C, int64_t ldc,
                        const float* bias, void* aux, float alpha, int64_t M, int64_t N, int64_t K,
                        int32_t epilogue, void* stream);
@@ -220,18 +223,19 @@ int32_t vipant_gemm_bias_residual_bwd(const uint16_t* dy, const uint16_t* w_t, c
                                       int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K5 -- ln_2 + c_fc + QuickGELU + c_proj (cvap/module/val.py:502-506, 521; clip/model.py:163-165).
- * h bf16 [M,D] = LN(x (+ add)); u bf16 [M,4D] = h . w_fc^T + b_fc; g = u * sigmoid(1.702 u); y bf16 [M,D] = g . w_proj^T + b_proj. */
+ * h bf16 [M,D] = LN(x (+ add)); u = h . w_fc^T + b_fc; g bf16 [M,4D] = u * sigmoid(1.702 u); dcode uint8 [M,4D] = 8-bit code of
+ * QuickGELU'(u) (all the backward needs of u: VIPANT_EPI_QUICKGELU_D8); y bf16 [M,D] = g . w_proj^T + b_proj. */
 int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
                                     const uint16_t* w_fc, const float* b_fc, const uint16_t* w_proj, const float* b_proj,
-                                    uint16_t* h, float* mean, float* rstd, uint16_t* u, uint16_t* g, uint16_t* y, int64_t M,
+                                    uint16_t* h, float* mean, float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M,
                                     int64_t D, void* stream);
-/* u, g again from the saved h (activation-memory plan `running.recompute_mlp`). */
-int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint16_t* u, uint16_t* g,
+/* dcode, g again from the saved h (activation-memory plan `running.recompute_mlp`). */
+int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode, uint16_t* g,
                                        int64_t M, int64_t D, void* stream);
 /* dy bf16 [M,D] = gradient of the MLP branch output (= bf16 copy of the stream gradient); dstream as in vipant_ln_qkv_bwd;
  * du bf16 [M,4D], dh bf16 [M,D] scratch; dw_proj fp32 [D,4D], dw_fc fp32 [4D,D], db_fc fp32 [4D];
  * dx_colsum (optional fp32 [D]) = d out_proj.bias. */
-int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t, const uint16_t* u,
+int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t, const uint8_t* dcode,
                                     const uint16_t* g, const uint16_t* h, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* du, uint16_t* dh,
                                     float* dw_proj, float* dw_fc, float* db_fc, float* dgamma, float* dbeta, float* dx_colsum,

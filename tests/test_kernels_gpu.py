@@ -100,6 +100,33 @@ def test_gemm_nt_fused_epilogues(ops):
     assert_close(out, ref, 1e-2, 2e-2, "dquickgelu")
 
 
+def qgelu_prime(u):
+    sg = torch.sigmoid(1.702 * u)
+    return sg * (1 + 1.702 * u * (1 - sg))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 3072, 768), (300, 264, 128), (70000, 1024, 256)])
+def test_gemm_nt_quickgelu_derivative_code(ops, M, N, K):
+    """The two-output epilogues with the 8-bit QuickGELU' code (what the step uses): g as before; the code decodes to
+    QuickGELU'(pre-activation) within half a code step (2.4e-3) plus the bf16 rounding of the pre-activation; the backward
+    epilogue multiplies by the decoded derivative."""
+    a = rnd(M, K, seed=31, dtype=torch.bfloat16); b = rnd(N, K, seed=32, dtype=torch.bfloat16, scale=2.0 * K ** -0.5)
+    bias = rnd(N, seed=33)
+    pre = a.float() @ b.float().t() + bias
+    code = torch.empty(M, N, dtype=torch.uint8, device=DEV); g = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, g, bias=bias, aux=code, epi=ops.EPI_QUICKGELU_D8)
+    assert_close(g, pre * torch.sigmoid(1.702 * pre), 1e-2, 2e-2, "quickgelu.g")
+    dec = code.float() / 212.5 - 0.1
+    assert float((dec - qgelu_prime(pre)).abs().max()) < 2.4e-3 + 6e-3, float((dec - qgelu_prime(pre)).abs().max())
+    assert float((dec - qgelu_prime(pre)).abs().mean()) < 2e-3
+    acc = a.float() @ b.float().t()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, out, aux=code, epi=ops.EPI_DQUICKGELU_D8)
+    assert_close(out, acc * dec, 1e-2, 2e-2, "dquickgelu from the code")
+    with pytest.raises(Exception):          # K = 64 has no ping-pong kernel: the code epilogues refuse instead of falling back
+        ops.gemm_nt(a[:, :64], b[:, :64], g, bias=bias, aux=code, epi=ops.EPI_QUICKGELU_D8)
+
+
 @pytest.mark.parametrize("M,N,K", [(4100, 2304, 768), (5000, 200, 64), (4096, 3072, 128), (6001, 776, 1024),
                                    (20000, 1000, 128), (66000, 256, 64)])   # >= 256 tiles with a short last round: half-tile tail kernel
 def test_gemm_nt_short_k_large_m(ops, M, N, K):

@@ -44,6 +44,9 @@ cases.append(("nt out  res32  N=768  K=768 ", 2 * M * 768 * 768, lambda: ops.gem
 cases.append(("nt fc   gelu   N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_nt(x768, w_fc, o3072, bias=bias3072, aux=u3072, epi=ops.EPI_QUICKGELU)))
 cases.append(("nt proj res32  N=768  K=3072", 2 * M * 768 * 3072, lambda: ops.gemm_nt(x3072, w_pr, r768b, bias=bias768, aux=r768, epi=ops.EPI_RESIDUAL_F32)))
 cases.append(("nt dgelu       N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_nt(x768, w_fc, o3072, aux=u3072, epi=ops.EPI_DQUICKGELU)))
+c3072 = torch.empty(M, 3072, dtype=torch.uint8, device=dev)
+cases.append(("nt fc   gelu8  N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_nt(x768, w_fc, o3072, bias=bias3072, aux=c3072, epi=ops.EPI_QUICKGELU_D8)))
+cases.append(("nt dgelu8      N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_nt(x768, w_fc, o3072, aux=c3072, epi=ops.EPI_DQUICKGELU_D8)))
 cases.append(("nt dh2  bf16   N=768  K=3072", 2 * M * 768 * 3072, lambda: ops.gemm_nt(x3072, w_pr, o768, epi=ops.EPI_BF16)))
 cases.append(("nt dh1  bf16   N=768  K=2304", 2 * M * 768 * 2304, lambda: ops.gemm_nt(x2304, rb(768, 2304, scale=0.02), o768, epi=ops.EPI_BF16)))
 cases.append(("tn dWo         P=768  Q=768 ", 2 * M * 768 * 768, lambda: ops.gemm_tn(x768, o768, g768)))

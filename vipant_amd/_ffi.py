@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIPANT_HIP_LIB") or os.path.join(_HERE, "lib", "libvipant_hip.so")   # override: A/B timing of builds
 
-EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32 = range(6)
+EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32, EPI_QUICKGELU_D8, EPI_DQUICKGELU_D8 = range(8)
 
 _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 

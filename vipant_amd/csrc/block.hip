@@ -85,23 +85,23 @@ extern "C" int32_t vipant_gemm_bias_residual_bwd(const uint16_t* dy, const uint1
 extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma,
                                                const float* beta, const uint16_t* w_fc, const float* b_fc,
                                                const uint16_t* w_proj, const float* b_proj, uint16_t* h, float* mean,
-                                               float* rstd, uint16_t* u, uint16_t* g, uint16_t* y, int64_t M, int64_t D,
+                                               float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M, int64_t D,
                                                void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: add and x_out go together");
     TRY(vipant_layernorm_fwd(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, stream));
-    TRY(vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, u, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU, stream));
+    TRY(vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, dcode, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream));
     return vipant_gemm_nt(g, 4 * D, w_proj, 4 * D, y, D, b_proj, nullptr, 1.0f, M, D, 4 * D, VIPANT_EPI_BF16, stream);
 }
 
-// The [M, 4D] activations u, g alone, from the saved LayerNorm output (`running.recompute_mlp`: they were not kept).
-extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint16_t* u,
+// The [M, 4D] activations (QuickGELU' codes, g) alone, from the saved LayerNorm output (`running.recompute_mlp`: they were not kept).
+extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,
                                                   uint16_t* g, int64_t M, int64_t D, void* stream) {
-    return vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, u, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU, stream);
+    return vipant_gemm_nt(h, D, w_fc, D, g, 4 * D, b_fc, dcode, 1.0f, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream);
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t,
-                                               const uint16_t* u, const uint16_t* g, const uint16_t* h, const float* x,
+                                               const uint8_t* dcode, const uint16_t* g, const uint16_t* h, const float* x,
                                                const float* mean, const float* rstd, const float* gamma, float* dstream,
                                                uint16_t* dx_bf16, uint16_t* du, uint16_t* dh, float* dw_proj, float* dw_fc,
                                                float* db_fc, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
@@ -109,9 +109,10 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE,
                    "ln_mlp_quickgelu_bwd: workspace too small");
-    // du = (dy . W_proj) * QuickGELU'(u);  dW_proj = dy^T g   (d b_proj is the column sum the caller already has)
-    TRY(vipant_gemm_nt(dy, D, w_proj_t, D, du, 4 * D, nullptr, const_cast<uint16_t*>(u), 1.0f, M, 4 * D, D,
-                       VIPANT_EPI_DQUICKGELU, stream));
+    // du = (dy . W_proj) * QuickGELU'(u), the derivative read from its 8-bit code;  dW_proj = dy^T g   (d b_proj is the column
+    // sum the caller already has)
+    TRY(vipant_gemm_nt(dy, D, w_proj_t, D, du, 4 * D, nullptr, const_cast<uint8_t*>(dcode), 1.0f, M, 4 * D, D,
+                       VIPANT_EPI_DQUICKGELU_D8, stream));
     TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
     TRY(vipant_gemm_nt(du, 4 * D, w_fc_t, 4 * D, dh, D, nullptr, nullptr, 1.0f, M, D, 4 * D, VIPANT_EPI_BF16, stream));

@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_bias(const GemmNT& p, int cn0, int wn, int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n4 = cn0 + wn * 64 + j * 16 + fq * 4;
-        bv[j] = (EPI != VIPANT_EPI_DQUICKGELU && p.bias != nullptr && n4 < p.N) ? *(const f32x4*)(p.bias + n4)
+        bv[j] = (EPI != VIPANT_EPI_DQUICKGELU && EPI != VIPANT_EPI_DQUICKGELU_D8 && p.bias != nullptr && n4 < p.N) ? *(const f32x4*)(p.bias + n4)
                                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -305,6 +305,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
     }
 }
 
+// QuickGELU'(u) = sg (1 + 1.702 u (1 - sg)), sg = sigmoid(1.702 u), lies in (-0.0998, 1.0998).  The backward needs only this
+// derivative, never u itself, so the forward can leave an 8-bit linear code of it instead of the bf16 pre-activation (1 instead of
+// 2 bytes per element in both two-output epilogues): code = round((d + 0.1) * 212.5), step 4.7e-3, error <= 2.4e-3 -- the size of
+// the bf16 rounding du carries anyway.
+__device__ __forceinline__ uint32_t gelu_code(float d) {
+    const float c = fminf(fmaxf((d + 0.1f) * 212.5f + 0.5f, 0.f), 255.f);
+    return (uint32_t)c;
+}
+__device__ __forceinline__ float gelu_decode(uint32_t c) { return (float)c * (1.0f / 212.5f) - 0.1f; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------------------------
 // Ping-pong persistent kernel (bf16-output epilogues, K >= 128).
 //
@@ -512,17 +523,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         const int tl = tid & 255;
-        bf16x8 un[4];                                // DQUICKGELU: pre-activations of the next round, loaded one round ahead
+        constexpr bool GELU_OUT = EPI == VIPANT_EPI_QUICKGELU || EPI == VIPANT_EPI_QUICKGELU_D8;
+        constexpr bool GELU_IN = EPI == VIPANT_EPI_DQUICKGELU || EPI == VIPANT_EPI_DQUICKGELU_D8;
+        constexpr bool D8 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
+        // QuickGELU' inputs of the next round (bf16 pre-activations, or their 8-bit derivative codes), loaded one round ahead
+        bf16x8 un[4];
+        u32x2 cn[4];
         auto load_aux = [&](int r) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int idx = t * 256 + tl;
                 const int R = idx >> 5, ch = idx & 31;
                 const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + ch * 8;
-                un[t] = (m < p.M && n < p.N) ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
+                const bool ok = m < p.M && n < p.N;
+                if (D8) cn[t] = ok ? *(const u32x2*)((const uint8_t*)p.aux + (int64_t)m * p.ldc + n) : u32x2{0u, 0u};
+                else un[t] = ok ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
             }
         };
-        if (EPI == VIPANT_EPI_DQUICKGELU) load_aux(0);
+        if (GELU_IN) load_aux(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -537,10 +555,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             }
             sync();
             bf16x8 u8[4];
-            if (EPI == VIPANT_EPI_DQUICKGELU) {      // this round's pre-activations arrived during the previous round
+            u32x2 c8[4];
+            if (GELU_IN) {      // this round's inputs arrived during the previous round
 #pragma unroll
-                for (int t = 0; t < 4; ++t) u8[t] = un[t];
+                for (int t = 0; t < 4; ++t) { u8[t] = un[t]; c8[t] = cn[t]; }
                 if (r + 1 < 4) load_aux(r + 1);
+            }
+            if (EPI == VIPANT_EPI_QUICKGELU_D8 && (p.N & 15) == 0 && (p.ldc & 15) == 0) {
+                // a thread takes 16 consecutive columns, so that the code leaves as one 16-B store per thread (the store path
+                // is bound by instructions as much as by bytes: 6 instead of 8 store instructions per thread and round)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int idx = t * 256 + tl;
+                    const int R = idx >> 4, cp = idx & 15;
+                    const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + cp * 16;
+                    if (m < p.M && n < p.N && !(p.dbg & 1)) {
+                        const int64_t o = (int64_t)m * p.ldc + n;
+                        uint32_t cw[4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const bf16x8 v = *(const bf16x8*)(stg + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
+                            bf16x8 g;
+                            uint32_t code[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float u = (float)v[e];
+                                const float sg = fast_sigmoid(1.702f * u);
+                                g[e] = (bf16_t)(u * sg);
+                                code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
+                            }
+                            cw[h * 2] = code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24;
+                            cw[h * 2 + 1] = code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24;
+                            *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
+                        }
+                        *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
+                    }
+                }
+                sync();
+                continue;
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -552,22 +604,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     const int64_t o = (int64_t)m * p.ldc + n;
                     if (EPI == VIPANT_EPI_BF16) {
                         *(bf16x8*)((bf16_t*)p.C + o) = v;
-                    } else if (EPI == VIPANT_EPI_QUICKGELU) {
-                        *(bf16x8*)((bf16_t*)p.aux + o) = v;
+                    } else if (GELU_OUT) {
                         bf16x8 g;
+                        uint32_t code[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float u = (float)v[e];
-                            g[e] = (bf16_t)(u * fast_sigmoid(1.702f * u));
+                            const float sg = fast_sigmoid(1.702f * u);
+                            g[e] = (bf16_t)(u * sg);
+                            code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
                         }
+                        if (D8)
+                            *(u32x2*)((uint8_t*)p.aux + o) = u32x2{code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24,
+                                                                   code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
+                        else
+                            *(bf16x8*)((bf16_t*)p.aux + o) = v;
                         *(bf16x8*)((bf16_t*)p.C + o) = g;
-                    } else {  // VIPANT_EPI_DQUICKGELU
+                    } else {  // QuickGELU'
                         bf16x8 d;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float u = (float)u8[t][e];
-                            const float sg = fast_sigmoid(1.702f * u);
-                            d[e] = (bf16_t)((float)v[e] * (sg * (1.0f + 1.702f * u * (1.0f - sg))));
+                            float dg;
+                            if (D8) {
+                                dg = gelu_decode((c8[t][e >> 2] >> ((e & 3) * 8)) & 255u);
+                            } else {
+                                const float u = (float)u8[t][e];
+                                const float sg = fast_sigmoid(1.702f * u);
+                                dg = sg * (1.0f + 1.702f * u * (1.0f - sg));
+                            }
+                            d[e] = (bf16_t)((float)v[e] * dg);
                         }
                         *(bf16x8*)((bf16_t*)p.C + o) = d;
                     }
@@ -670,6 +735,13 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: dquickgelu epilogue needs aux (U in)");
             if (pp) return launch_pp<VIPANT_EPI_DQUICKGELU>(p, s);
             return staged ? launch_persistent<VIPANT_EPI_DQUICKGELU>(p, s) : launch<VIPANT_EPI_DQUICKGELU>(p, s);
+        case VIPANT_EPI_QUICKGELU_D8:
+        case VIPANT_EPI_DQUICKGELU_D8:
+            VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: the 8-bit QuickGELU' epilogues need aux (the code matrix)");
+            VIPANT_REQUIRE(staged && K >= 128 && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
+                           "gemm_nt: the 8-bit QuickGELU' epilogues need N %% 8 == 0, ldc %% 8 == 0, K >= 128 and a 16-byte aligned aux");
+            return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp<VIPANT_EPI_QUICKGELU_D8>(p, s)
+                                                        : launch_pp<VIPANT_EPI_DQUICKGELU_D8>(p, s);
         case VIPANT_EPI_SCALE_F32: return launch<VIPANT_EPI_SCALE_F32>(p, s);
         default:
             vipant_set_error("gemm_nt: unknown epilogue %d", epilogue);
