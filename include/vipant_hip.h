@@ -108,6 +108,11 @@ int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t*
 /* ---- elementwise / layout helpers ------------------------------------------------------------------
  * fp32 -> bf16 cast of a [R, C] matrix; dst_t (optional) receives the transpose [C, R]. */
 int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t R, int64_t C, void* stream);
+/* The same for a list of matrices in one launch (all weight matrices of a tower once per step): device arrays of ntensors device
+ * pointers src / dst / dst_t (entries of dst or dst_t may be NULL), row / column counts R, C, and tile_start[ntensors + 1], the
+ * running sum of ceil(R/64) * ceil(C/64); total_tiles = tile_start[ntensors]. */
+int32_t vipant_cast_bf16_multi(const float* const* src, uint16_t* const* dst, uint16_t* const* dst_t, const int32_t* R,
+                               const int32_t* C, const int32_t* tile_start, int64_t ntensors, int64_t total_tiles, void* stream);
 /* bf16 -> fp32 widening of n elements (n % 4 == 0). */
 int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
 /* conv1.weight [O, Cin, kh, kw] fp32 -> effective GEMM weight bf16 [O, Cout*kh*kw]; mean_channels != 0

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_cast_bf16_multi": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "vipant_cast_f32": (_i32, [_p, _p, _i64, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "vipant_conv_weight_prep": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),

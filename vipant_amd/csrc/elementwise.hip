@@ -39,6 +39,71 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// All the weight matrices of a tower in ONE launch (48 small launches of the kernel above cost ~1 ms per step): workgroup ->
+// (tensor, 64x64 tile) through a prefix table of tile counts; 16-B loads, 8-B stores of the straight copy, the transposed copy
+// through LDS.
+struct CastMulti {
+    const float* const* src; bf16_t* const* dst; bf16_t* const* dst_t;
+    const int32_t* R; const int32_t* C; const int32_t* tile_start;      // tile_start[n + 1]
+    int n;
+};
+__global__ __launch_bounds__(256) void cast_multi_kernel(CastMulti a) {
+    __shared__ bf16_t tile[64][68];
+    int lo = 0, hi = a.n;                        // largest t with tile_start[t] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int t = lo;
+    const int R = a.R[t], C = a.C[t];
+    const int tcols = (C + 63) / 64;
+    const int local = (int)blockIdx.x - a.tile_start[t];
+    const int tr = (local / tcols) * 64, tc = (local % tcols) * 64;
+    const float* src = a.src[t];
+    bf16_t* dst = a.dst[t];
+    bf16_t* dst_t = a.dst_t[t];
+    const int cx = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;          // 16 threads x 4 columns per row, 16 rows per pass
+    const bool vec = (C & 3) == 0;
+#pragma unroll
+    for (int r = ry; r < 64; r += 16) {
+        const int gr = tr + r, gc = tc + cx;
+        bf16x4 v = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (gr < R) {
+            if (vec && gc + 3 < C) {
+                v = f32x4_to_bf16x4(*(const f32x4*)(src + (int64_t)gr * C + gc));
+                if (dst != nullptr) *(bf16x4*)(dst + (int64_t)gr * C + gc) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gc + e < C) {
+                        v[e] = (bf16_t)src[(int64_t)gr * C + gc + e];
+                        if (dst != nullptr) dst[(int64_t)gr * C + gc + e] = v[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][cx + e] = v[e];
+    }
+    __syncthreads();
+    if (dst_t == nullptr) return;
+    const bool vect = (R & 3) == 0;
+#pragma unroll
+    for (int c = ry; c < 64; c += 16) {           // output row = source column tc + c, 4 consecutive source rows per thread
+        const int gc = tc + c, gr = tr + cx;
+        if (gc >= C) continue;
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[cx + e][c];
+        if (vect && gr + 3 < R) {
+            *(bf16x4*)(dst_t + (int64_t)gc * R + gr) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gr + e < R) dst_t[(int64_t)gc * R + gr + e] = v[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void residual_add_kernel(const float* __restrict__ x, const bf16_t* __restrict__ add,
                                                            float* __restrict__ out, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -286,6 +351,16 @@ extern "C" int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* d
         hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(C, 64), (unsigned)ceil_div(R, 64)), dim3(256), 0,
                            s, src, (bf16_t*)dst, (bf16_t*)dst_t, (int)R, (int)C);
     }
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_cast_bf16_multi(const float* const* src, uint16_t* const* dst, uint16_t* const* dst_t,
+                                          const int32_t* R, const int32_t* C, const int32_t* tile_start, int64_t ntensors,
+                                          int64_t total_tiles, void* stream) {
+    VIPANT_REQUIRE(ntensors > 0 && total_tiles > 0 && total_tiles < (1ll << 31), VIPANT_EBADSHAPE, "cast_bf16_multi: empty");
+    CastMulti a{src, (bf16_t* const*)dst, (bf16_t* const*)dst_t, R, C, tile_start, (int)ntensors};
+    hipLaunchKernelGGL(cast_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

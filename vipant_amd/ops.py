@@ -193,6 +193,49 @@ def cast_bf16_flat(x: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+class _WeightCaster:
+    """bf16 copies (W and W^T) of a list of fp32 weight matrices, refreshed by ONE launch (vipant_cast_bf16_multi).  The output
+    buffers and the device pointer tables are built once per parameter set and reused every step."""
+
+    def __init__(self, weights: Sequence[torch.Tensor]):
+        dev = weights[0].device
+        self.key = tuple(w.data_ptr() for w in weights)
+        self.keep = [w.untyped_storage() for w in weights]       # the addresses stay ours while this entry lives
+        shapes = [(w.shape[0], w.numel() // w.shape[0]) for w in weights]
+        self.wb = [torch.empty(s, dtype=BF16, device=dev) for s in shapes]
+        self.wt = [torch.empty((s[1], s[0]), dtype=BF16, device=dev) for s in shapes]
+        starts = [0]
+        for r, c in shapes:
+            starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+        self.total = starts[-1]
+        self.src = torch.tensor([w.data_ptr() for w in weights], dtype=I64, device=dev)
+        self.dst = torch.tensor([t.data_ptr() for t in self.wb], dtype=I64, device=dev)
+        self.dst_t = torch.tensor([t.data_ptr() for t in self.wt], dtype=I64, device=dev)
+        self.R = torch.tensor([s[0] for s in shapes], dtype=torch.int32, device=dev)
+        self.C = torch.tensor([s[1] for s in shapes], dtype=torch.int32, device=dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32, device=dev)
+        self.n = len(weights)
+
+    def refresh(self):
+        call("vipant_cast_bf16_multi", self.src.data_ptr(), self.dst.data_ptr(), self.dst_t.data_ptr(), self.R.data_ptr(),
+             self.C.data_ptr(), self.starts.data_ptr(), self.n, self.total, _stream())
+        return self.wb, self.wt
+
+
+_casters: Dict[tuple, _WeightCaster] = {}
+
+
+def cast_weights(weights: Sequence[torch.Tensor]):
+    """(list of bf16 W, list of bf16 W^T) for the trainable matrices of a tower, one launch."""
+    key = tuple(w.data_ptr() for w in weights)
+    c = _casters.get(key)
+    if c is None:
+        while len(_casters) >= 16:
+            _casters.pop(next(iter(_casters)))
+        c = _casters[key] = _WeightCaster([w.detach() for w in weights])
+    return c.refresh()
+
+
 _frozen_cache: Dict[tuple, tuple] = {}
 
 
@@ -320,11 +363,13 @@ class BackboneFn(torch.autograd.Function):
         if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
+        if train:               # bf16 copies (W and W^T) of the 4 L weight matrices: one launch per step
+            wb_all, wt_all = cast_weights([params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)])
         for l in range(L):
             ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
             if train:
-                wqkv_b, wqkv_t = cast_bf16(wqkv, True); wo_b, wo_t = cast_bf16(wo, True)
-                wfc_b, wfc_t = cast_bf16(wfc, True); wpr_b, wpr_t = cast_bf16(wpr, True)
+                wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4]
+                wqkv_t, wo_t, wfc_t, wpr_t = wt_all[4 * l:4 * l + 4]
                 wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None))
                 h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
                 mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
