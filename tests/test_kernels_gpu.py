@@ -42,6 +42,34 @@ def assert_close(got, ref, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(100, 64, 192), (257, 2304, 128), (129, 520, 128), (40000, 256, 192)])
+def test_gemm_nt_pingpong_edges(ops, M, N, K):
+    """Corners of the ping-pong kernel's K-tile stream: two / three K-tiles per tile (the stream wraps into the next tile inside
+    the look-ahead), fewer rows than one wave group, a single tile, N tails, many tiles per workgroup."""
+    a = rnd(M, K, seed=41, dtype=torch.bfloat16); b = rnd(N, K, seed=42, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=43)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, c, bias=bias, epi=ops.EPI_BF16)
+    assert_close(c, a.float() @ b.float().t() + bias, 1e-2, 2e-2, "bf16 epilogue")
+    c2 = torch.empty_like(c)
+    ops.gemm_nt(a, b, c2, bias=bias, epi=ops.EPI_BF16)
+    assert torch.equal(c, c2)
+
+
+def test_weight_casts(ops):
+    """One multi-tensor launch == the per-matrix cast (bf16 copy and transposed bf16 copy), and the bf16 -> fp32 widening."""
+    ws = [rnd(768, 768, seed=1), rnd(2304, 768, seed=2), rnd(100, 36, seed=3), rnd(64, 3072, seed=4), rnd(7, 5, seed=5)]
+    wb, wt = ops.cast_weights(ws)
+    for w, b1, t1 in zip(ws, wb, wt):
+        b0, t0 = ops.cast_bf16(w, True)
+        assert torch.equal(b0, b1) and torch.equal(t0, t1), tuple(w.shape)
+        assert torch.equal(t1, w.to(torch.bfloat16).t().contiguous())
+    x = rnd(1000, 768, seed=6, dtype=torch.bfloat16)
+    y = torch.empty(1000, 768, device=DEV)
+    ops.call("vipant_cast_f32", x.data_ptr(), y.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(y, x.float())
+
+
 @pytest.mark.parametrize("M,N,K", [(992, 768, 768), (256, 256, 64), (1000, 2304, 768), (516, 512, 1536), (4096, 3072, 768),
                                    (33, 768, 3072)])
 def test_gemm_nt_plain(ops, M, N, K):

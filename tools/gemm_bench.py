@@ -49,6 +49,8 @@ cases.append(("nt fc   gelu8  N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.ge
 cases.append(("nt dgelu8      N=3072 K=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_nt(x768, w_fc, o3072, aux=c3072, epi=ops.EPI_DQUICKGELU_D8)))
 cases.append(("nt dh2  bf16   N=768  K=3072", 2 * M * 768 * 3072, lambda: ops.gemm_nt(x3072, w_pr, o768, epi=ops.EPI_BF16)))
 cases.append(("nt dh1  bf16   N=768  K=2304", 2 * M * 768 * 2304, lambda: ops.gemm_nt(x2304, rb(768, 2304, scale=0.02), o768, epi=ops.EPI_BF16)))
+w_o2 = rb(768, 768, scale=0.03)
+cases.append(("nt out  bf16   N=768  K=768 ", 2 * M * 768 * 768, lambda: ops.gemm_nt(x768, w_o2, o768, bias=bias768, epi=ops.EPI_BF16)))
 cases.append(("tn dWo         P=768  Q=768 ", 2 * M * 768 * 768, lambda: ops.gemm_tn(x768, o768, g768)))
 cases.append(("tn dWfc        P=3072 Q=768 ", 2 * M * 3072 * 768, lambda: ops.gemm_tn(x3072, x768, g3072a)))
 cases.append(("tn dWproj      P=768  Q=3072", 2 * M * 768 * 3072, lambda: ops.gemm_tn(x768, x3072, g3072b)))
