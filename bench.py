@@ -189,7 +189,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
           f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
     cfg = compose(ov)
-    cfg.rank = local_rank
+    cfg.rank = rank
     torch.manual_seed(cfg.seed)
     mon = VALMonitor(cfg, (lambda *_: None), dev)
     mon.total_loss = mon.total_step = mon.total_inst = 0
@@ -244,12 +244,17 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; with fewer visible GPUs than ranks (the 2-rank test on a 1-GPU box) ranks share devices round-robin
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)      # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("VIPANT_DIST_BACKEND", "nccl")        # "nccl" = RCCL over xGMI; "gloo" only for the shared-GPU test
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from vipant_amd import _ffi, ops
     from vipant_amd.config import compose
@@ -269,7 +274,7 @@ def main():
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
     cfg = compose(ov)
-    cfg.rank = local_rank
+    cfg.rank = rank
     torch.manual_seed(cfg.seed)
     mon = VAMonitor(cfg, (lambda *_: None), dev)
     mon.total_loss = mon.total_step = mon.total_inst = 0

@@ -175,3 +175,30 @@ def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path):
     # update direction: bf16 towers against the fp32 oracle at b = 8 -- typical tensor a few %, the noisiest (near-cancelling
     # bias gradients) observed at 0.20
     assert dirs[len(dirs) // 2] < 5e-2 and dirs[-1] < 0.3, (dirs[len(dirs) // 2], dirs[-1])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("script", ["va", "at"])
+def test_bench_two_ranks_share_the_gpu(script):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on the one GPU of this box:
+    the ranks share cuda:0 and talk over gloo (`VIPANT_DIST_BACKEND=gloo`; RCCL refuses two ranks on one device).  Checks the
+    N > 1 code path of the bench end to end -- group set-up, feature all-gather, bucketed gradient reduction, barrier, max-over-
+    ranks timing, the one JSON line -- not its speed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIPANT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16", "--frames", "256", "--mels", "64", "--layers", "2", "--no-cpu-baseline", "--script", script]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]                 # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 32 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    import math
+    nneg = 32 if script == "va" else 16            # va: global (all-gathered) negatives; at: every rank scores its own 16
+    assert math.isfinite(out["loss"]) and abs(out["loss"] - 2 * math.log(nneg)) < 1.0, out["loss"]
