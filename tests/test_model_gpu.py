@@ -411,3 +411,67 @@ def test_activation_memory_plans_keep_the_step():
     for k in p0:
         err = float((p0[k] - p2[k]).abs().max())
         assert err <= 1e-6 + 1e-4 * float(p0[k].abs().max()), (k, err)
+
+
+@pytest.mark.parametrize("tag", ["va", "at"])
+def test_trainer_trajectory_golden(M, golden, tag):
+    """Four optimisation steps of the product path -- heads, loss head, fused LARS, `adjust_learning_rate` -- against the
+    trajectory the REFERENCE's own pieces produced on the same weights and batches (tests/golden/make_golden.py, section viii):
+    learning rates exactly, every step's loss, every tunable tensor's update norm, and the final small tensors."""
+    g = golden(f"traj_{tag}")
+    L, b, T, Fq = 2, 8, 256, 64
+    head = M.build_audio_head(audio_cfg(T, Fq, L))
+    S = head.misc.positional_embedding.shape[0]
+    w0 = gen.det_weights(f"traj/{tag}", gen.vit_head_shapes(768, L, 512, S))
+    head.load_state_dict(w0, strict=True)
+    if tag == "at":
+        thead = M.build_text_head(text_cfg(L))
+        thead.load_state_dict(gen.det_weights("traj/text", gen.text_head_shapes(512, L, 512)), strict=True)
+        thead = thead.to(DEV).eval()
+        for p in thead.parameters():
+            p.requires_grad = False
+        lhead = M.build_loss_head(NS(name="VALCELossHead", layers=[], scaling=True, scale_max=None, va=False, lv=False, al=True))
+    else:
+        lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
+    head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
+    named = [(f"audio_head.{k}", p) for k, p in head.named_parameters()] + [(f"loss_head.{k}", p) for k, p in lhead.named_parameters()]
+    assert [k for k, _ in named] == list(g["keys"])
+    params = [p for _, p in named]
+    opt = M.LARS([{"params": [p for p in params if p.ndim > 1]}, {"params": [p for p in params if p.ndim < 2]}], lr=0.,
+                 weight_decay=1e-6, weight_decay_filter=M.exclude_bias_or_norm, lars_adaptation_filter=M.exclude_bias_or_norm)
+    ocfg = NS(epochs=3, warmup_epoch=1, batch_size=b, lr_weight=0.2, lr_bias=0.0048)
+    from vipant_amd import ops
+    worst_loss, worst_norm = 0.0, 0.0
+    for step in range(4):
+        M.adjust_learning_rate(ocfg, opt, range(2), step)
+        assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][step][0])) < 1e-9 and abs(opt.param_groups[1]["lr"] - float(g["lrs"][step][1])) < 1e-10
+        before = [p.detach().clone() for p in params]
+        opt.zero_grad(set_to_none=True)
+        feat = head(gen.det_randn(f"traj/{tag}/aud/{step}", (b, 1, T, Fq)).to(DEV), normalized=True)
+        if tag == "at":
+            with torch.no_grad():
+                tf = thead(gen.det_tokens(f"traj/tok/{step}", b).to(DEV), normalized=True)
+            loss = lhead(None, feat, tf, normalized=True)
+        else:
+            loss = lhead(ops.l2_normalize(gen.det_randn(f"traj/{tag}/img/{step}", (b, 512)).to(DEV)), feat, None, normalized=True)
+        loss.backward()
+        opt.step()
+        worst_loss = max(worst_loss, abs(float(loss) - float(g["losses"][step])))
+        for i, (p, q) in enumerate(zip(params, before)):
+            ref = float(g["dnorm"][step][i])
+            dn = float((p.detach() - q).norm())
+            if ref == 0.0:
+                assert dn == 0.0, (step, named[i][0])
+            else:
+                worst_norm = max(worst_norm, abs(dn / ref - 1))
+    observe(f"traj_{tag}", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
+    assert worst_loss < 5e-3, worst_loss                  # b = 8: the bf16 towers' loss error at this batch size (observed ~2e-3)
+    assert worst_norm < 6e-2, worst_norm                  # update norms: LARS trust ratio x gradient norm, bf16 gradient noise
+    for k, p in named:
+        if f"final_{k}" in g.files:
+            k0 = k[len("audio_head."):] if k.startswith("audio_head.") else None
+            init = w0[k0] if k0 is not None else torch.ones([]) * math.log(1 / 0.07)
+            d_ref = torch.from_numpy(g[f"final_{k}"]).double() - init.double()
+            d_hip = p.detach().cpu().double() - init.double()
+            if float(d_ref.norm()) > 0:
+                assert float((d_hip - d_ref).norm() / d_ref.norm()) < 0.25, k      # accumulated update direction of a small tensor

@@ -210,3 +210,47 @@ def test_zero_shot_report(golden):
     mapped = torch.tensor([perm[int(v)] for v in lab])
     assert R.zero_shot_report(feats, mapped, prompts, label_map=perm) == str(g["zero_shot_mapped"])
 
+
+
+@pytest.mark.parametrize("tag", ["va", "at"])
+def test_trainer_trajectory(golden, tag):
+    """Four optimisation steps (warm-up into cosine, LARS) of the reference's own heads / loss head / optimizer, VA and AT
+    layouts: the oracle's forward, autograd and `lars_step` / `adjust_learning_rate` reproduce every step's learning rates,
+    loss and per-tensor update norm, and the final values of the small tensors."""
+    g = golden(f"traj_{tag}")
+    L, b, T, Fq = 2, 8, 256, 64
+    stride, S, pr = R.vit_position_resolution([T, Fq], 32, [16, 24])
+    asd = {k: v.clone().requires_grad_() for k, v in gen.det_weights(f"traj/{tag}", gen.vit_head_shapes(768, L, 512, S)).items()}
+    ls = torch.tensor(float(np.log(1 / 0.07)), requires_grad=True)
+    lkey = "loss_head.loss_head_al.logit_scale" if tag == "at" else "loss_head.logit_scale"
+    named = [(f"audio_head.{k}", v) for k, v in asd.items()] + [(lkey, ls)]
+    order = {k: i for i, k in enumerate(list(g["keys"]))}
+    assert set(order) == {k for k, _ in named}
+    tsd = gen.det_weights("traj/text", gen.text_head_shapes(512, L, 512)) if tag == "at" else None
+    mus = {k: torch.zeros_like(v) for k, v in named}
+    for step in range(4):
+        lw, lb = R.adjust_learning_rate(step, epochs=3, steps_per_epoch=2, warmup_epoch=1, batch_size=b, lr_weight=0.2,
+                                        lr_bias=0.0048)
+        close([lw, lb], g["lrs"][step], 1e-6, 1e-12)
+        aud = gen.det_randn(f"traj/{tag}/aud/{step}", (b, 1, T, Fq))
+        feat = R.vit_head_forward(aud, asd, width=768, layers=L, stride=stride, position_resolution=pr)
+        if tag == "at":
+            with torch.no_grad():
+                tf = R.text_head_forward(gen.det_tokens(f"traj/tok/{step}", b), tsd, width=512, layers=L, ctx_len=77)
+            loss = R.valce_loss_head(None, feat, tf, {"al": ls}, va=False, lv=False, al=True)
+        else:
+            loss = R.ce_loss_head(R.l2_normalize(gen.det_randn(f"traj/{tag}/img/{step}", (b, 512))), feat, ls)
+        for _, v in named:
+            v.grad = None
+        loss.backward()
+        assert abs(float(loss) - float(g["losses"][step])) < 2e-4, (step, float(loss), float(g["losses"][step]))
+        with torch.no_grad():
+            for k, v in named:
+                p_new, mus[k] = R.lars_step(v.detach(), v.grad, mus[k], lw if v.ndim > 1 else lb)
+                dn = float((p_new - v.detach()).norm())
+                ref = float(g["dnorm"][step][order[k]])
+                assert abs(dn - ref) <= 1e-7 + 2e-3 * ref, (step, k, dn, ref)
+                v.copy_(p_new)
+    for k, v in named:
+        if f"final_{k}" in g.files:
+            close(v.detach(), g[f"final_{k}"], 1e-4, 1e-6)
