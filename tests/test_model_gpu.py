@@ -475,3 +475,24 @@ def test_trainer_trajectory_golden(M, golden, tag):
             d_hip = p.detach().cpu().double() - init.double()
             if float(d_ref.norm()) > 0:
                 assert float((d_hip - d_ref).norm() / d_ref.norm()) < 0.25, k      # accumulated update direction of a small tensor
+
+
+def test_frozen_towers_full_depth_golden(M, golden):
+    """Both frozen towers at their full 12-block depth against the reference's features (forward-only path: cached bf16 weights,
+    one set of temporaries, causal attention with the EOT read-out for the text tower)."""
+    g = golden("towers_l12")
+    thead = M.build_text_head(text_cfg(12))
+    thead.load_state_dict(gen.det_weights("text/l12", gen.text_head_shapes(512, 12, 512)), strict=True)
+    ihead = M.build_image_head(image_cfg(12))
+    ihead.load_state_dict(gen.det_weights("img/l12", gen.vit_head_shapes(768, 12, 512, 50)), strict=True)
+    thead, ihead = thead.to(DEV).eval(), ihead.to(DEV).eval()
+    with torch.no_grad():
+        tf = thead(gen.det_tokens("text/l12/tok", 6).to(DEV), normalized=True)
+        ts = thead(gen.det_tokens("text/l12/short", 5, L=40)[:, :40].contiguous().to(DEV), normalized=True)
+        imf = ihead(gen.det_randn("img/l12/x", (3, 3, 224, 224)).to(DEV), normalized=True)
+    errs = dict(text=rel_err(tf, g["text_feat"]), text_short=rel_err(ts, g["text_feat_short"]), image=rel_err(imf, g["image_feat"]))
+    observe("towers_l12", **errs)
+    assert max(errs.values()) < 3e-2, errs                     # 12 bf16 blocks: observed ~1 % of the largest component
+    for got, ref in ((tf, g["text_feat"]), (ts, g["text_feat_short"]), (imf, g["image_feat"])):
+        cos = torch.nn.functional.cosine_similarity(got.double().cpu(), torch.from_numpy(ref).double(), dim=-1)
+        assert float(cos.min()) > 0.999, float(cos.min())

@@ -254,3 +254,19 @@ def test_trainer_trajectory(golden, tag):
     for k, v in named:
         if f"final_{k}" in g.files:
             close(v.detach(), g[f"final_{k}"], 1e-4, 1e-6)
+
+
+def test_frozen_towers_full_depth(golden):
+    """The frozen CLIP text transformer (12 blocks, causal, EOT read-out; full-width and short batches) and ViT-B/32 image tower
+    (12 blocks) against the reference's features."""
+    g = golden("towers_l12")
+    tsd = gen.det_weights("text/l12", gen.text_head_shapes(512, 12, 512))
+    isd = gen.det_weights("img/l12", gen.vit_head_shapes(768, 12, 512, 50))
+    tok = gen.det_tokens("text/l12/tok", 6)
+    assert int(tok.sum()) == int(g["tok_sum"])
+    with torch.no_grad():
+        close(R.text_head_forward(tok, tsd, width=512, layers=12, ctx_len=77), g["text_feat"], 2e-4, 2e-6)
+        close(R.text_head_forward(gen.det_tokens("text/l12/short", 5, L=40)[:, :40], tsd, width=512, layers=12, ctx_len=77),
+              g["text_feat_short"], 2e-4, 2e-6)
+        close(R.vit_head_forward(gen.det_randn("img/l12/x", (3, 3, 224, 224)), isd, width=768, layers=12, stride=[32, 32],
+                                 position_resolution=(7, 7)), g["image_feat"], 2e-4, 2e-6)
