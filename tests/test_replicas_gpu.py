@@ -202,3 +202,30 @@ def test_bench_two_ranks_share_the_gpu(script):
     import math
     nneg = 32 if script == "va" else 16            # va: global (all-gathered) negatives; at: every rank scores its own 16
     assert math.isfinite(out["loss"]) and abs(out["loss"] - 2 * math.log(nneg)) < 1.0, out["loss"]
+
+
+@pytest.mark.timeout(900)
+def test_train_entry_two_ranks_share_the_gpu(tmp_path):
+    """`train.py` with the VA launch script's overrides under torch.distributed.run, two ranks on this box's one GPU (gloo):
+    group set-up from the environment, per-rank synthetic batches, the replica exchange steps inside Monitor.epoch, rank-0 logging
+    and checkpoint; both ranks must end with the same weights (rank 1 writes a second checkpoint for the comparison)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIPANT_DIST_BACKEND="gloo")
+    ov = (f"+running=bimodal worker=CVALP mode=ddp eval=False verbose=False alias_root={tmp_path} model_name=t num_gpus=2 "
+          "+model/image=vit_val +model/audio=vit_val +model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default "
+          "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=1 "
+          "running.audio.max_len=256 running.audio.num_mel_bins=64 running.batch_size=4 running.synthetic_steps=2 "
+          "running.epochs=1 running.peep_rate=1 running.frame_emb=synthetic running.save_rate=2").split()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "train.py")] + ov
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    log = (tmp_path / "t" / "train_0.out").read_text()
+    assert "World size: 2; rank: 0" in log and "samples/s" in log and "Saving the checkpoint" in log
+    assert (tmp_path / "t" / "train_1.out").exists()
+    ck = torch.load(tmp_path / "t" / "00000002.pth", weights_only=False)
+    assert len(ck["model"]) == 4 and "encoder.resblocks.0.attn.in_proj_weight" in ck["model"][1]
+    lines = [ln for ln in log.splitlines() if "samples/s" in ln]
+    assert len(lines) == 2 and "step 2" in lines[-1]

@@ -36,9 +36,13 @@ def main(cfg, rank, device, manager):
 def train(argv=None):
     cfg = compose(sys.argv[1:] if argv is None else argv)
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 or cfg.mode == "ddp" and "RANK" in os.environ:
-        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+        local_rank = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("VIPANT_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for shared-GPU tests
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
         try:
             main(cfg, dist.get_rank(), torch.device("cuda", local_rank), cfg.monitor)
         finally:

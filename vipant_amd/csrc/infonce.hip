@@ -25,7 +25,7 @@ using namespace ntcore;
 
 struct NceWs {       // carved out of the caller's workspace; all offsets 256-B aligned
     bf16_t *x1cat, *x2cat, *dz, *dzt;
-    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part;   // scal[0] = s, scal[1] = clamped
+    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part, *dxtmp;   // scal[0] = s, scal[1] = clamped
     void* tn_ws;
     size_t tn_bytes, total;
     int Bp, rparts, cparts;
@@ -51,6 +51,7 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     w.diag = (float*)take((size_t)B * 4); w.rlse = (float*)take((size_t)B * 4); w.clse = (float*)take((size_t)B * 4);
     w.scal = (float*)take(256);
     w.part = (float*)take((size_t)ceil_div(B, 16) * 2 * 4);
+    w.dxtmp = (float*)take((size_t)(B + 8) * E * 4);          // gradient rows of a strip that does not start on a multiple of 8
     w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
     w.tn_ws = take(w.tn_bytes);
     w.total = off;
@@ -292,8 +293,8 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
                                           int64_t B, int64_t E, int64_t row0, int64_t nrows, void* workspace,
                                           size_t workspace_bytes, void* stream) {
     VIPANT_REQUIRE(B > 0 && E > 0 && E % 64 == 0, VIPANT_EBADSHAPE, "infonce: need E %% 64 == 0 (B=%ld E=%ld)", (long)B, (long)E);
-    VIPANT_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= B && row0 % 8 == 0, VIPANT_EBADSHAPE,
-                   "infonce: bad row slice [%ld, %ld) of %ld (row0 must be a multiple of 8)", (long)row0, (long)(row0 + nrows), (long)B);
+    VIPANT_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= B, VIPANT_EBADSHAPE,
+                   "infonce: bad row slice [%ld, %ld) of %ld", (long)row0, (long)(row0 + nrows), (long)B);
     VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_infonce_workspace_bytes(B, E), VIPANT_ENOWORKSPACE,
                    "infonce: workspace too small");
     VIPANT_REQUIRE((uintptr_t)workspace % 256 == 0, VIPANT_EALIGN, "infonce: workspace must be 256-byte aligned");
@@ -319,21 +320,29 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(256), 0, s, w, (int)B, nparts, grad_scale, loss, dlogit_scale);
     VIPANT_LAUNCH_CHECK();
     if ((dx1 == nullptr && dx2 == nullptr) || nrows == 0) return VIPANT_OK;
+    // The token-reduction contraction wants its A operand 16-byte aligned, i.e. a strip starting on a multiple of 8 columns: a
+    // rank's strip that does not (the reference's shipped default is 432 clips over 4 GPUs = 108 per rank) is widened to the left
+    // by up to 7 columns, contracted into a scratch matrix, and its own rows copied out.
+    const int64_t r0a = row0 & ~(int64_t)7, lead = row0 - r0a, nr = nrows + lead;
     if (dx2 != nullptr) {     // s dZ [m][n], columns n in the strip;  dx2[n, :] = sum_m s dZ[m][n] x1[m, :]
-        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)row0, (int)nrows, grad_scale);
+        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)r0a, (int)nr, grad_scale);
         VIPANT_LAUNCH_CHECK();
-        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + row0), w.Bp, (const uint16_t*)w.x1cat, 3 * E, dx2, E, B,
-                                         nrows, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
+        float* out = lead ? w.dxtmp : dx2;
+        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + r0a), w.Bp, (const uint16_t*)w.x1cat, 3 * E, out, E, B,
+                                         nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
+        if (lead) VIPANT_HIP_TRY(hipMemcpyAsync(dx2, out + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (dx1 != nullptr) {     // the same kernel on (x2, x1) with the LSE vectors swapped writes s dZ^T [n][m], columns m in the strip
         NceWs t = w;
         t.x1cat = w.x2cat; t.x2cat = w.x1cat; t.rlse = w.clse; t.clse = w.rlse; t.dz = w.dzt;
-        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)row0, (int)nrows, grad_scale);
+        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)r0a, (int)nr, grad_scale);
         VIPANT_LAUNCH_CHECK();
-        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dzt + row0), w.Bp, (const uint16_t*)w.x2cat, 3 * E, dx1, E, B,
-                                         nrows, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
+        float* out = lead ? w.dxtmp : dx1;
+        const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dzt + r0a), w.Bp, (const uint16_t*)w.x2cat, 3 * E, out, E, B,
+                                         nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
+        if (lead) VIPANT_HIP_TRY(hipMemcpyAsync(dx1, out + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return VIPANT_OK;
 }
