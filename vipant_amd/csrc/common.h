@@ -73,7 +73,12 @@ __device__ __forceinline__ bf16x4 f32x4_to_bf16x4(f32x4 v) {
     return r;
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// sigmoid(1.702 u), the gate of QuickGELU (clip/model.py:163-165), as v_exp_f32 + v_rcp_f32 (about 1 ulp each; the outputs are
+// rounded to bf16 anyway).  `__frcp_rn(x)` / `1.0f / x` expand to the IEEE division sequence -- 11 instructions per element,
+// which made the two-output epilogues VALU-bound (c_fc: 1167 -> 850 us with the arithmetic removed, round-2 probe).
+__device__ __forceinline__ float quickgelu_gate(float u) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * u));      // 1.702 * log2(e)
+}
 
 // 128-bit buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {

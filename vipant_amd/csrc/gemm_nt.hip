@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNT p) {
                 *(bf16x4*)((bf16_t*)p.aux + o) = f32x4_to_bf16x4(v);
                 f32x4 g;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = v[e] * fast_sigmoid(1.702f * v[e]);
+                for (int e = 0; e < 4; ++e) g[e] = v[e] * quickgelu_gate(v[e]);
                 *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(g);
             } else if (EPI == VIPANT_EPI_DQUICKGELU) {
                 const bf16x4 u4 = *(const bf16x4*)((const bf16_t*)p.aux + o);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float u = (float)u4[e];
-                    const float sg = fast_sigmoid(1.702f * u);
+                    const float sg = quickgelu_gate(u);
                     d[e] = acc[i][j][e] * (sg * (1.0f + 1.702f * u * (1.0f - sg)));
                 }
                 *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(d);
@@ -167,7 +167,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmNT& p, f32x4 (&acc)[8]
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float u = (float)v[e];
-                            g[e] = (bf16_t)(u * fast_sigmoid(1.702f * u));
+                            g[e] = (bf16_t)(u * quickgelu_gate(u));
                         }
                         *(bf16x8*)((bf16_t*)p.C + o) = g;
                     } else {  // VIPANT_EPI_DQUICKGELU
@@ -176,7 +176,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmNT& p, f32x4 (&acc)[8]
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float u = (float)u8[e];
-                            const float sg = fast_sigmoid(1.702f * u);
+                            const float sg = quickgelu_gate(u);
                             d[e] = (bf16_t)((float)v[e] * (sg * (1.0f + 1.702f * u * (1.0f - sg))));
                         }
                         *(bf16x8*)((bf16_t*)p.C + o) = d;
@@ -312,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persistent_kernel(GemmNT p) {
 __device__ __forceinline__ uint32_t gelu_code(float d) {
     const float c = fminf(fmaxf((d + 0.1f) * 212.5f + 0.5f, 0.f), 255.f);
     return (uint32_t)c;
+}
+// the same, converted and inserted into byte `pos` of `word` by one v_cvt_pk_u8_f32 (round to nearest, saturating)
+__device__ __forceinline__ uint32_t gelu_code_pack(float d, int pos, uint32_t word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(d, 212.5f, 21.25f), (uint32_t)pos, word);
 }
 __device__ __forceinline__ float gelu_decode(uint32_t c) { return (float)c * (1.0f / 212.5f) - 0.1f; }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -576,16 +580,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                         for (int h = 0; h < 2; ++h) {
                             const bf16x8 v = *(const bf16x8*)(stg + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
                             bf16x8 g;
-                            uint32_t code[8];
+                            cw[h * 2] = cw[h * 2 + 1] = 0u;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 const float u = (float)v[e];
-                                const float sg = fast_sigmoid(1.702f * u);
-                                g[e] = (bf16_t)(u * sg);
-                                code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
+                                const float sg = quickgelu_gate(u);
+                                const float ge = u * sg;
+                                g[e] = (bf16_t)ge;
+                                cw[h * 2 + (e >> 2)] = gelu_code_pack(__builtin_fmaf(1.702f * ge, 1.0f - sg, sg), e & 3, cw[h * 2 + (e >> 2)]);
                             }
-                            cw[h * 2] = code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24;
-                            cw[h * 2 + 1] = code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24;
                             *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
                         }
                         *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float u = (float)v[e];
-                            const float sg = fast_sigmoid(1.702f * u);
+                            const float sg = quickgelu_gate(u);
                             g[e] = (bf16_t)(u * sg);
                             code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
                         }
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                                 dg = gelu_decode((c8[t][e >> 2] >> ((e & 3) * 8)) & 255u);
                             } else {
                                 const float u = (float)u8[t][e];
-                                const float sg = fast_sigmoid(1.702f * u);
+                                const float sg = quickgelu_gate(u);
                                 dg = sg * (1.0f + 1.702f * u * (1.0f - sg));
                             }
                             d[e] = (bf16_t)((float)v[e] * dg);
