@@ -65,12 +65,13 @@ def parse():
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
                          "CLIP text tower at L=77, local negatives (run_bimodal_at.sh); extra measurement, not the headline")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=64)
     return ap.parse_args()
 
 
 def host_cpu():
-    """(model name, physical cores) of this box from lscpu; falls back to os.cpu_count()."""
+    """(model name, usable cores) of this box: lscpu's sockets x cores per socket, capped by the process's CPU affinity and by
+    the cgroup CPU quota."""
     import subprocess
     model, cores_per_socket, sockets = "unknown", None, None
     try:
@@ -86,6 +87,18 @@ def host_cpu():
     except Exception:
         pass
     physical = cores_per_socket * sockets if cores_per_socket and sockets else (os.cpu_count() or 1)
+    # the cores this process may actually use: CPU affinity and the cgroup CPU quota of the box (more threads than that are
+    # throttled: a 16-CPU quota under 128 threads ran the same sample 3-5x slower, and differently from run to run)
+    try:
+        physical = max(1, min(physical, len(os.sched_getaffinity(0))))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            physical = max(1, min(physical, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     return model, physical
 
 
