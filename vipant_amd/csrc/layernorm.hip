@@ -170,7 +170,8 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
                    "layernorm_fwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
     VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (int)(ceil_div(M, 4) > 2048 ? 2048 : ceil_div(M, 4));
+    // one row per wave, no grid-stride loop: 254 us against 286 us with 2048 persistent workgroups at M = 161 792 (1.49 GB)
+    const int blocks = (int)(ceil_div(M, 4) > (1 << 20) ? (1 << 20) : ceil_div(M, 4));
 #define LN_FWD(NV)                                                                                                   \
     hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, y_f32, mean, \
                        rstd, M, (const bf16_t*)add, sum_out)
