@@ -192,8 +192,21 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % d4) * 4;
         const int s = (int)(i / d4);
+        // eight samples per trip: eight independent loads in flight per thread (the one-sample loop was a 512-deep chain of
+        // dependent round trips: 382 us for 0.74 GB), summed in a fixed order (reproducible)
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int64_t bi = 0; bi < b; ++bi) {
+        int64_t bi = 0;
+        for (; bi + 8 <= b; bi += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(dtok + ((bi + j) * S + s) * D + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (s > 0) *(bf16x4*)(dpatches + ((bi + j) * P + s - 1) * D + c) = f32x4_to_bf16x4(v[j]);
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; bi < b; ++bi) {
             const f32x4 v = *(const f32x4*)(dtok + (bi * S + s) * D + c);
             acc += v;
             if (s > 0) *(bf16x4*)(dpatches + (bi * P + s - 1) * D + c) = f32x4_to_bf16x4(v);
