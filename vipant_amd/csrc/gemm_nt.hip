@@ -581,13 +581,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                             const bf16x8 v = *(const bf16x8*)(stg + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
                             bf16x8 g;
                             cw[h * 2] = cw[h * 2 + 1] = 0u;
+                            // two elements per instruction (v_pk_mul / v_pk_add / v_pk_fma): this epilogue is bound by its own
+                            // arithmetic as much as by its stores.  code = 212.5 (sg + 1.702 ge (1 - sg)) + 21.25, constants folded.
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float u = (float)v[e];
-                                const float sg = quickgelu_gate(u);
-                                const float ge = u * sg;
-                                g[e] = (bf16_t)ge;
-                                cw[h * 2 + (e >> 2)] = gelu_code_pack(__builtin_fmaf(1.702f * ge, 1.0f - sg, sg), e & 3, cw[h * 2 + (e >> 2)]);
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 u = f32x2{(float)v[e], (float)v[e + 1]};
+                                const f32x2 a = u * -2.4554669595930157f;
+                                const f32x2 b = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+                                const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+                                const f32x2 ge = u * sg;
+                                const f32x2 c = (ge * 361.675f) * (1.0f - sg) + (sg * 212.5f + 21.25f);
+                                g[e] = (bf16_t)ge[0];
+                                g[e + 1] = (bf16_t)ge[1];
+                                uint32_t& w = cw[h * 2 + (e >> 2)];
+                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
+                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
                             }
                             *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
                         }
