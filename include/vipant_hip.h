@@ -115,6 +115,19 @@ int32_t vipant_cast_bf16_multi(const float* const* src, uint16_t* const* dst, ui
                                const int32_t* C, const int32_t* tile_start, int64_t ntensors, int64_t total_tiles, void* stream);
 /* bf16 -> fp32 widening of n elements (n % 4 == 0). */
 int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
+/* fp8 operands (BASELINE.json configs[4], "fp8 MFMA weights"; the reference has no counterpart -- its contractions are the
+ * fp16 autocast matmuls of clip/model.py:170-187 -- so parity is against an exact emulation of this quantiser, tests/test_fp8_gpu.py).
+ * bf16 rows x [M, K] -> OCP e4m3 rows q [M, K] with one power-of-two scale per row: scale[m] = e + 127 where e is the smallest
+ * exponent with max|x[m, :]| / 2^e <= 448, q = round-to-nearest-even(x / 2^e).  K % 8 == 0. */
+int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                               void* stream);
+/* C[M, N] (bf16) = (A 2^(sa - 127)) (B 2^(sb - 127))^T (+ bias), A [M, K] and B [N, K] e4m3 with the row scales above, on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation; the row scales ride the instruction's block-scale operand).  Epilogues:
+ * VIPANT_EPI_BF16, VIPANT_EPI_QUICKGELU_D8, VIPANT_EPI_DQUICKGELU_D8, meaning as in vipant_gemm_nt.  K % 128 == 0, K >= 256,
+ * N % 8 == 0, leading dimensions (in elements = bytes) multiples of 16. */
+int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb,
+                            void* C, int64_t ldc, const float* bias, void* aux, int64_t M, int64_t N, int64_t K, int32_t epilogue,
+                            void* stream);
 /* conv1.weight [O, Cin, kh, kw] fp32 -> effective GEMM weight bf16 [O, Cout*kh*kw]; mean_channels != 0
  * averages the Cin stored channels into one (cvap/module/val.py:236-244), else Cout = Cin. */
 int32_t vipant_conv_weight_prep(const float* w, uint16_t* out, int64_t O, int64_t Cin, int64_t khw,

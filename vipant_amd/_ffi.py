@@ -39,6 +39,8 @@ PROTOTYPES = {
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_cast_bf16_multi": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "vipant_cast_f32": (_i32, [_p, _p, _i64, _p]),
+    "vipant_quant_e4m3_rows": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
+    "vipant_gemm_nt_e4m3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "vipant_conv_weight_prep": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_im2col": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),

@@ -22,6 +22,7 @@ struct GemmNT {
     int M, N, K;
     float alpha;
     int dbg;   // VIPANT_GEMM_VARIANT (timing experiments only): bit 0 = skip the epilogue stores
+    const uint8_t* sa; const uint8_t* sb;    // fp8 operands only: per-row E8M0 exponents of A and B (value = e4m3 * 2^(byte - 127))
 };
 
 template <int EPI>
@@ -350,7 +351,28 @@ constexpr int PP_B_BASE = 4 * PP_A_STAGE;                // 64 KiB: [group][stag
 constexpr int PP_B_SLOT = BN * BK * 2;                   // 32 KiB
 constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
 
-template <int EPI, int VAR>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// One v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands.  Operand layout (tools/probes/mx_layout_probe.hip, mx_scale_probe.hip,
+// exact integer data on the MI355X): lane (r = lane & 15, q = lane >> 4) holds bytes k = 16 q .. 16 q + 15 of row r in dwords
+// 0-3 and k = 64 + 16 q .. in dwords 4-7 -- the two 16-byte fragments the bf16 loop reads for its k-steps 0 and 1 of a 128-byte
+// row -- and its scale byte applies to row r, k in [32 q, 32 q + 32).  The byte of the scale register is picked by an
+// instruction immediate, hence the switch (it folds away once the tile loops are unrolled).
+__device__ __forceinline__ f32x4 mfma_e4m3(const i32x8& a, const i32x8& b, f32x4 c, int oa, uint32_t sa, int ob, uint32_t sb) {
+#define VIPANT_MX(OA, OB) case OA * 4 + OB: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, (int)sa, OB, (int)sb);
+    switch (oa * 4 + ob) {
+        VIPANT_MX(0, 0) VIPANT_MX(0, 1) VIPANT_MX(0, 2) VIPANT_MX(0, 3) VIPANT_MX(1, 0) VIPANT_MX(1, 1) VIPANT_MX(1, 2) VIPANT_MX(1, 3)
+        VIPANT_MX(2, 0) VIPANT_MX(2, 1) VIPANT_MX(2, 2) VIPANT_MX(2, 3) VIPANT_MX(3, 0) VIPANT_MX(3, 1) VIPANT_MX(3, 2)
+        default: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 3, (int)sa, 3, (int)sb);
+    }
+#undef VIPANT_MX
+}
+
+// ES = bytes per operand element: 2 = bf16 (K-tile of 64), 1 = e4m3 with per-row power-of-two scales (K-tile of 128: the same
+// 128-byte rows, the same LDS images, DMA stream and barrier schedule; half the MFMA instructions, each twice as long, for
+// twice the K -- twice the FLOP per byte moved and per cycle).
+template <int EPI, int VAR, int ES = 2>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     const int G = gridDim.x;                                   // multiple of 8, <= ntiles rounded up
     const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
-    const int nk = p.K / BK;
+    const int nk = p.K / (ES == 2 ? BK : 2 * BK);
 
     // DMA: wave fills row blocks wave*4 .. wave*4+3 (8 rows x 128 B) of the tile's A and B rows, as in the kernel above
     uint32_t voffA[2], voffB[2];
@@ -372,11 +394,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     for (int i = 0; i < 2; ++i) {
         const int r = i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        voffA[i] = (uint32_t)(r * p.lda * 2 + c * 16);
-        voffB[i] = (uint32_t)(r * p.ldb * 2 + c * 16);
+        voffA[i] = (uint32_t)(r * p.lda * ES + c * 16);
+        voffB[i] = (uint32_t)(r * p.ldb * ES + c * 16);
     }
-    const uint32_t waveA = (uint32_t)(wave * 32 * p.lda * 2), waveB = (uint32_t)(wave * 32 * p.ldb * 2);
-    const uint32_t pairA = (uint32_t)(16 * p.lda * 2), pairB = (uint32_t)(16 * p.ldb * 2);
+    const uint32_t waveA = (uint32_t)(wave * 32 * p.lda * ES), waveB = (uint32_t)(wave * 32 * p.ldb * ES);
+    const uint32_t pairA = (uint32_t)(16 * p.lda * ES), pairB = (uint32_t)(16 * p.ldb * ES);
     char* const ldsA = smem + grp * (2 * PP_A_STAGE) + wl * 4096;          // + stage * PP_A_STAGE
     char* const ldsB = smem + PP_B_BASE + wave * 4096;                      // + slot * PP_B_SLOT
     // fragment reads
@@ -391,19 +413,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // a tile's operand panels as (base pointer, byte range): scalars, so that "this tile or the next one" is a scalar select and
     // the buffer descriptor built from it stays in SGPRs (a select between two descriptors made hipcc keep them in VGPRs and
     // wrap every LDS-DMA in a readfirstlane loop)
-    struct TileDesc { const bf16_t* a; const bf16_t* b; uint32_t abytes, bbytes; int m0, n0; };
+    struct TileDesc { const char* a; const char* b; uint32_t abytes, bbytes; int m0, n0; };
     auto describe = [&](int tile) {
         TileDesc d;
         if (tile < ntiles) {
             const int tm = tile / ntn, tn = tile % ntn;
             d.m0 = tm * BM; d.n0 = tn * BN;
-            const int64_t a_bytes = ((int64_t)(p.M - d.m0) * p.lda - (p.lda - p.K)) * 2;
-            const int64_t b_bytes = ((int64_t)(p.N - d.n0) * p.ldb - (p.ldb - p.K)) * 2;
-            d.a = p.A + (int64_t)d.m0 * p.lda; d.abytes = (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes);
-            d.b = p.B + (int64_t)d.n0 * p.ldb; d.bbytes = (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes);
+            const int64_t a_bytes = ((int64_t)(p.M - d.m0) * p.lda - (p.lda - p.K)) * ES;
+            const int64_t b_bytes = ((int64_t)(p.N - d.n0) * p.ldb - (p.ldb - p.K)) * ES;
+            d.a = (const char*)p.A + (int64_t)d.m0 * p.lda * ES; d.abytes = (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes);
+            d.b = (const char*)p.B + (int64_t)d.n0 * p.ldb * ES; d.bbytes = (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes);
         } else {                                   // past the last tile: zero records, every lane out of range, no traffic
             d.m0 = p.M; d.n0 = 0;
-            d.a = p.A; d.b = p.B; d.abytes = 0; d.bbytes = 0;
+            d.a = (const char*)p.A; d.b = (const char*)p.B; d.abytes = 0; d.bbytes = 0;
         }
         return d;
     };
@@ -448,10 +470,63 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
+    // e4m3 operands: the K-tile is one 128-deep MFMA step; the two barrier intervals take row tiles 0-3 and 4-7 of the wave
+    // (16 MFMAs of 32 cycles each, the length of the 32 bf16 MFMAs they replace).  The B fragments (both 16-byte halves of four
+    // column tiles) are read in the first interval and kept; A fragments run one row tile (four MFMAs, 128 cycles) ahead.
+    i32x8 gb[4], ga[2];
+    uint32_t sav[2] = {0x7F7F7F7Fu, 0x7F7F7F7Fu}, sbv = 0x7F7F7F7Fu, sav_n[2] = {0x7F7F7F7Fu, 0x7F7F7F7Fu}, sbv_n = 0x7F7F7F7Fu;
+    auto load_scales = [&](const TileDesc& d, uint32_t (&a2)[2], uint32_t& b1) {     // row tile i -> byte i, column tile j -> byte j
+        a2[0] = a2[1] = b1 = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = d.m0 + grp * 128 + i * 16 + frow;
+            a2[i >> 2] |= (uint32_t)(m < p.M ? p.sa[m] : (uint8_t)127) << ((i & 3) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = d.n0 + wl * 64 + j * 16 + frow;
+            b1 |= (uint32_t)(n < p.N ? p.sb[n] : (uint8_t)127) << (j * 8);
+        }
+    };
+    auto frag_head8 = [&](int h, int stage, int slot) {
+        const char* sa0 = smem + stage * PP_A_STAGE + offA[0] + h * 4 * 2048;
+        const char* sa1 = smem + stage * PP_A_STAGE + offA[1] + h * 4 * 2048;
+        if (h == 0) {
+            const char* sb0 = smem + slot * PP_B_SLOT + offB[0];
+            const char* sb1 = smem + slot * PP_B_SLOT + offB[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gb[j].lo = *(const i32x4*)(sb0 + j * 2048);
+                gb[j].hi = *(const i32x4*)(sb1 + j * 2048);
+            }
+        }
+        ga[0].lo = *(const i32x4*)(sa0);
+        ga[0].hi = *(const i32x4*)(sa1);
+    };
+    auto half_body8 = [&](int h, int stage) {
+        const char* sa0 = smem + stage * PP_A_STAGE + offA[0] + h * 4 * 2048;
+        const char* sa1 = smem + stage * PP_A_STAGE + offA[1] + h * 4 * 2048;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            if (ii + 1 < 4) {
+                ga[(ii + 1) & 1].lo = *(const i32x4*)(sa0 + (ii + 1) * 2048);
+                ga[(ii + 1) & 1].hi = *(const i32x4*)(sa1 + (ii + 1) * 2048);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[h * 4 + ii][j] = mfma_e4m3(gb[j], ga[ii & 1], acc[h * 4 + ii][j], j, sbv, ii, sav[h]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     int tile = lane_pos;
     TileDesc cur = describe(tile), nxt = describe(tile + G);
     int gk = 0, slot = 0;                       // K-tile counter of the stream: A stage = gk & 1, B slot = gk % 3
+    if (ES == 1) {
+        load_scales(cur, sav, sbv);
+        asm volatile("" : "+v"(sav[0]), "+v"(sav[1]), "+v"(sbv));             // awaited before any DMA is in flight
+    }
     // prologue: K-tile 0 of the first tile (and, for group 1, its B rows of K-tile 1)
     fill_a(make_rsrc(cur.a, cur.abytes), 0, 0);
     fill_b(make_rsrc(cur.b, cur.bbytes), 0, 0);
@@ -476,8 +551,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
+                if (ES == 1) load_scales(nxt, sav_n, sbv_n);                  // the next tile's scales ride the same round trip
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
+                if (ES == 1) asm volatile("" : "+v"(sav_n[0]), "+v"(sav_n[1]), "+v"(sbv_n));
             }
             {   // first interval: DMA of the stream's next K-tile(s), k-step 0
                 const bool w1 = k + 1 >= nk, w2 = k + 2 >= nk;
@@ -503,9 +580,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dma_piece(i);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ES == 1) frag_head8(0, stage, slot); else
                     frag_head(0, stage, slot);
                 }
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                if (ES == 1) half_body8(0, stage); else
                 if (VAR == 3) half_body(0, stage, dma_piece); else
                 half_body(0, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
@@ -513,8 +592,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 sync();
             }
             {   // second interval: k-step 1
+                if (ES == 1) frag_head8(1, stage, slot); else
                 frag_head(1, stage, slot);
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                if (ES == 1) half_body8(1, stage); else
                 half_body(1, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -654,21 +735,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         tile += G;
         cur = nxt;
         nxt = describe(tile + G);
+        if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; sbv = sbv_n; }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
 }
 
-template <int EPI, int VAR>
+template <int EPI, int VAR, int ES = 2>
 int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
         configured = true;
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -726,7 +808,7 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
     VIPANT_REQUIRE(256 * lda * 2 < (1ll << 31) && 256 * ldb * 2 < (1ll << 31), VIPANT_EBADSHAPE,
                    "gemm_nt: leading dimension too large");
     static const int dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
-    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg};
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     const bool staged = (N % 8 == 0) && (ldc % 8 == 0) && !(dbg & 2);
     const bool pp = staged && K >= 128 && !(dbg & 16);
@@ -756,6 +838,35 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
         case VIPANT_EPI_SCALE_F32: return launch<VIPANT_EPI_SCALE_F32>(p, s);
         default:
             vipant_set_error("gemm_nt: unknown epilogue %d", epilogue);
+            return VIPANT_EBADSHAPE;
+    }
+}
+
+// e4m3 x e4m3 -> bf16: C = (A * 2^(sa - 127)) (B * 2^(sb - 127))^T [+ bias], the ping-pong kernel at ES = 1.
+extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb,
+                                       const uint8_t* sb, void* C, int64_t ldc, const float* bias, void* aux, int64_t M, int64_t N,
+                                       int64_t K, int32_t epilogue, void* stream) {
+    VIPANT_REQUIRE(M > 0 && N > 0 && K > 0, VIPANT_EBADSHAPE, "gemm_nt_e4m3: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    VIPANT_REQUIRE(K % 128 == 0 && K >= 256 && N % 8 == 0, VIPANT_EBADSHAPE,
+                   "gemm_nt_e4m3: need K %% 128 == 0, K >= 256 and N %% 8 == 0 (K=%ld N=%ld)", (long)K, (long)N);
+    VIPANT_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0, VIPANT_EALIGN,
+                   "gemm_nt_e4m3: bad leading dims lda=%ld ldb=%ld ldc=%ld", (long)lda, (long)ldb, (long)ldc);
+    VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), VIPANT_EALIGN,
+                   "gemm_nt_e4m3: operands must be 16-byte aligned");
+    VIPANT_REQUIRE(sa != nullptr && sb != nullptr, VIPANT_EBADSHAPE, "gemm_nt_e4m3: the row scales of both operands are required");
+    VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, sa, sb};
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case VIPANT_EPI_BF16: return launch_pp_variant<VIPANT_EPI_BF16, 0, 1>(p, s);
+        case VIPANT_EPI_QUICKGELU_D8:
+        case VIPANT_EPI_DQUICKGELU_D8:
+            VIPANT_REQUIRE(aux != nullptr && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
+                           "gemm_nt_e4m3: the 8-bit QuickGELU' epilogues need a 16-byte aligned aux (the code matrix)");
+            return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1>(p, s)
+                                                        : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1>(p, s);
+        default:
+            vipant_set_error("gemm_nt_e4m3: epilogue %d is not built for e4m3 operands (bf16 and the two 8-bit QuickGELU' ones are)", epilogue);
             return VIPANT_EBADSHAPE;
     }
 }

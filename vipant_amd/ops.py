@@ -95,6 +95,31 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux
     return c
 
 
+def quant_e4m3(x: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor = None):
+    """bf16 rows [M, K] -> (e4m3 bytes [M, K], E8M0 row-scale bytes [M]); see vipant_quant_e4m3_rows."""
+    _need(x, BF16, "quant_e4m3.x")
+    M, K = x.shape
+    if q is None:
+        q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((M,), dtype=torch.uint8, device=x.device)
+    call("vipant_quant_e4m3_rows", x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), M, K, _stream())
+    return q, scale
+
+
+def gemm_nt_e4m3(a, sa, b, sb, c: torch.Tensor, *, bias=None, aux=None, epi: int = EPI_BF16):
+    """c[M,N] (bf16) = dequant(a, sa) @ dequant(b, sb)^T with the epilogue `epi`: e4m3 operands, row scales from quant_e4m3."""
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and sa.dtype == torch.uint8 and sb.dtype == torch.uint8
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and tuple(c.shape) == (M, N) and sa.numel() == M and sb.numel() == N, (a.shape, b.shape, c.shape)
+    if aux is not None:
+        assert aux.stride(0) == c.stride(0)
+    call("vipant_gemm_nt_e4m3", a.data_ptr(), a.stride(0), sa.data_ptr(), b.data_ptr(), b.stride(0), sb.data_ptr(), c.data_ptr(),
+         c.stride(0), _ptr(bias), _ptr(aux), M, N, K, epi, _stream())
+    return c
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, accumulate: bool = False, a_colsum=None,
             ws_name: str = "gemm_tn"):
     """c[P,Q] (+)= a[M,P]^T @ b[M,Q] (fp32 out); a_colsum (fp32 [P], optional) (+)= column sums of a.
