@@ -354,20 +354,15 @@ constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// One v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands.  Operand layout (tools/probes/mx_layout_probe.hip, mx_scale_probe.hip,
+// v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands.  Operand layout (tools/probes/mx_layout_probe.hip, mx_scale_probe.hip,
 // exact integer data on the MI355X): lane (r = lane & 15, q = lane >> 4) holds bytes k = 16 q .. 16 q + 15 of row r in dwords
 // 0-3 and k = 64 + 16 q .. in dwords 4-7 -- the two 16-byte fragments the bf16 loop reads for its k-steps 0 and 1 of a 128-byte
 // row -- and its scale byte applies to row r, k in [32 q, 32 q + 32).  The byte of the scale register is picked by an
-// instruction immediate, hence the switch (it folds away once the tile loops are unrolled).
-__device__ __forceinline__ f32x4 mfma_e4m3(const i32x8& a, const i32x8& b, f32x4 c, int oa, uint32_t sa, int ob, uint32_t sb) {
-#define VIPANT_MX(OA, OB) case OA * 4 + OB: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, (int)sa, OB, (int)sb);
-    switch (oa * 4 + ob) {
-        VIPANT_MX(0, 0) VIPANT_MX(0, 1) VIPANT_MX(0, 2) VIPANT_MX(0, 3) VIPANT_MX(1, 0) VIPANT_MX(1, 1) VIPANT_MX(1, 2) VIPANT_MX(1, 3)
-        VIPANT_MX(2, 0) VIPANT_MX(2, 1) VIPANT_MX(2, 2) VIPANT_MX(2, 3) VIPANT_MX(3, 0) VIPANT_MX(3, 1) VIPANT_MX(3, 2)
-        default: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 3, (int)sa, 3, (int)sb);
-    }
-#undef VIPANT_MX
-}
+// instruction immediate, so the call sites are spelled out with literal selectors (a `switch` on the unrolled loop index
+// compiled, but left the MFMAs in blocks of their own, and the machine sinker then moved all 32 of a K-tile below both barriers).
+template <int V> struct Int { static constexpr int value = V; };
+#define VIPANT_MX(ACC, A, B, OA, SA, OB, SB) \
+    ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, ACC, 0, 0, OA, (int)(SA), OB, (int)(SB))
 
 // ES = bytes per operand element: 2 = bf16 (K-tile of 64), 1 = e4m3 with per-row power-of-two scales (K-tile of 128: the same
 // 128-byte rows, the same LDS images, DMA stream and barrier schedule; half the MFMA instructions, each twice as long, for
@@ -488,9 +483,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             b1 |= (uint32_t)(n < p.N ? p.sb[n] : (uint8_t)127) << (j * 8);
         }
     };
-    auto frag_head8 = [&](int h, int stage, int slot) {
+    auto frag_head8 = [&](auto hc, int stage, int slot) {
+        constexpr int h = decltype(hc)::value;
         const char* sa0 = smem + stage * PP_A_STAGE + offA[0] + h * 4 * 2048;
         const char* sa1 = smem + stage * PP_A_STAGE + offA[1] + h * 4 * 2048;
+        ga[0].lo = *(const i32x4*)(sa0);          // first: the first MFMA waits for these and gb[0] only (LDS returns in order)
+        ga[0].hi = *(const i32x4*)(sa1);
         if (h == 0) {
             const char* sb0 = smem + slot * PP_B_SLOT + offB[0];
             const char* sb1 = smem + slot * PP_B_SLOT + offB[1];
@@ -500,24 +498,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 gb[j].hi = *(const i32x4*)(sb1 + j * 2048);
             }
         }
-        ga[0].lo = *(const i32x4*)(sa0);
-        ga[0].hi = *(const i32x4*)(sa1);
     };
-    auto half_body8 = [&](int h, int stage) {
+    auto half_body8 = [&](auto hc, int stage) {
+        constexpr int h = decltype(hc)::value;
         const char* sa0 = smem + stage * PP_A_STAGE + offA[0] + h * 4 * 2048;
         const char* sa1 = smem + stage * PP_A_STAGE + offA[1] + h * 4 * 2048;
+        const uint32_t sah = sav[h];
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            if (ii + 1 < 4) {
-                ga[(ii + 1) & 1].lo = *(const i32x4*)(sa0 + (ii + 1) * 2048);
-                ga[(ii + 1) & 1].hi = *(const i32x4*)(sa1 + (ii + 1) * 2048);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[h * 4 + ii][j] = mfma_e4m3(gb[j], ga[ii & 1], acc[h * 4 + ii][j], j, sbv, ii, sav[h]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+#define VIPANT_MX_ROW(II)                                                                  \
+        if (II + 1 < 4) {                                                                  \
+            ga[(II + 1) & 1].lo = *(const i32x4*)(sa0 + (II + 1) * 2048);                  \
+            ga[(II + 1) & 1].hi = *(const i32x4*)(sa1 + (II + 1) * 2048);                  \
+        }                                                                                  \
+        VIPANT_MX(acc[h * 4 + II][0], gb[0], ga[II & 1], 0, sbv, II, sah);                 \
+        VIPANT_MX(acc[h * 4 + II][1], gb[1], ga[II & 1], 1, sbv, II, sah);                 \
+        VIPANT_MX(acc[h * 4 + II][2], gb[2], ga[II & 1], 2, sbv, II, sah);                 \
+        VIPANT_MX(acc[h * 4 + II][3], gb[3], ga[II & 1], 3, sbv, II, sah);                 \
+        __builtin_amdgcn_sched_barrier(0);
+        VIPANT_MX_ROW(0) VIPANT_MX_ROW(1) VIPANT_MX_ROW(2) VIPANT_MX_ROW(3)
+#undef VIPANT_MX_ROW
     };
 
     int tile = lane_pos;
@@ -580,11 +579,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dma_piece(i);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ES == 1) frag_head8(0, stage, slot); else
+                    if (ES == 1) frag_head8(Int<0>{}, stage, slot); else
                     frag_head(0, stage, slot);
                 }
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
-                if (ES == 1) half_body8(0, stage); else
+                if (ES == 1) half_body8(Int<0>{}, stage); else
                 if (VAR == 3) half_body(0, stage, dma_piece); else
                 half_body(0, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
@@ -592,10 +591,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 sync();
             }
             {   // second interval: k-step 1
-                if (ES == 1) frag_head8(1, stage, slot); else
+                if (ES == 1) frag_head8(Int<1>{}, stage, slot); else
                 frag_head(1, stage, slot);
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
-                if (ES == 1) half_body8(1, stage); else
+                if (ES == 1) half_body8(Int<1>{}, stage); else
                 half_body(1, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
