@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--width", type=int, default=D, help="audio tower width (heads = width // 64, cvap/module/val.py:474); "
                     "1024 with --layers 24 is the audio ViT-L of BASELINE configs[4]")
     ap.add_argument("--recompute-mlp", action="store_true", help="running.recompute_mlp: MLP activations re-made in the backward")
+    ap.add_argument("--fp8", action="store_true", help="running.fp8_gemm: e4m3 operands in the audio tower's NT contractions "
+                                                       "(BASELINE.json configs[4]; never the headline line, which is bf16)")
     ap.add_argument("--micro-batch", type=int, default=0, help="running.micro_batch: towers in micro-batches under one loss")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--script", choices=["va", "at"], default="va",
@@ -197,7 +199,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
           "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True "
           f"running.imagine=False model.loss.va=False model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} +running.negatives=local "
-          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} "
+          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
           f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -237,13 +239,13 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
                       + 12 * 77 * (24 * 512 * 512 + 4 * 77 * 512) + 2 * 512 * E) + 6.0 * b * b * E
     out = {"metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "vs_baseline": None, "dtype": "e4m3 NT contractions, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"AT fine-tuning step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT width "
                                   f"{args.width} / {args.layers}L fwd+bwd + frozen CLIP text tower (L=77) fwd + InfoNCE(al) + LARS, local "
                                   "negatives (BASELINE.json configs[2]; configs[4]'s tower with --width 1024 --layers 24, bf16 weights); "
                                   "NOT the headline configuration",
                       "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local",
-                      "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch)},
+                      "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch), "fp8_gemm": bool(args.fp8)},
            "loss": round(float(loss.detach()), 4), "step_tflops": round(algo_flops / (ms * 1e-3) / 1e12, 1),
            "step_mfma_frac": round(algo_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
@@ -282,7 +284,7 @@ def main():
           "+model/loss=ce +optimizer=standard +running/audio=default model.audio.pre_encoder.in_channels=3 "
           f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} "
-          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} "
+          f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} "
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -334,7 +336,8 @@ def main():
     out = {
         "metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "e4m3 NT contractions, bf16 elsewhere (NOT the headline precision)" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"VA pretrain step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-{'B' if W == 768 else W}/{args.layers}L "
                                "fwd+bwd + frozen CLIP ViT-B/32 image tower fwd + InfoNCE + LARS (BASELINE.json configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",

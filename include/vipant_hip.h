@@ -259,6 +259,46 @@ int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t
                                     float* dw_proj, float* dw_fc, float* db_fc, float* dgamma, float* dbeta, float* dx_colsum,
                                     int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- The same block operators with e4m3 operands in their NT contractions (BASELINE.json configs[4], "fp8 MFMA weights") ----
+ * `plan` carries the pre-quantised weights (vipant_quant_e4m3_rows of the SAME matrices, in the SAME orientation, as the bf16
+ * weight arguments, which are then unused and may be NULL) and the scratch the operator quantises its activation into; every NT
+ * contraction becomes quantise(activation rows) + vipant_gemm_nt_e4m3.  The weight-gradient contractions, LayerNorm, the
+ * attention core and the residual stream are unchanged (bf16 / fp32).  plan == NULL: exactly the bf16 operator.
+ * w_q / w_scale: the operator's (first) weight; w2_q / w2_scale: the second weight of the MLP operators (forward: w_fc then w_proj;
+ * backward: w_proj_t then w_fc_t); act_q: bytes [M, 4D] (the widest activation); act_scale: bytes [M]. */
+typedef struct vipant_fp8_plan {
+    const uint8_t* w_q;
+    const uint8_t* w_scale;
+    const uint8_t* w2_q;
+    const uint8_t* w2_scale;
+    uint8_t* act_q;
+    uint8_t* act_scale;
+} vipant_fp8_plan;
+int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+                               const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd, uint16_t* qkv,
+                               int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x, const float* mean,
+                               const float* rstd, const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* dh, float* dw,
+                               float* db, float* dgamma, float* dbeta, float* dx_colsum, int64_t M, int64_t D, void* workspace,
+                               size_t workspace_bytes, const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_gemm_bias_residual_fwd_e4m3(const uint16_t* a, const uint16_t* w, const float* bias, const float* residual, void* out,
+                                           int64_t M, int64_t N, int64_t K, const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_gemm_bias_residual_bwd_e4m3(const uint16_t* dy, const uint16_t* w_t, const uint16_t* a, uint16_t* da, float* dw,
+                                           int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
+                                           const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+                                         const uint16_t* w_fc, const float* b_fc, const uint16_t* w_proj, const float* b_proj,
+                                         uint16_t* h, float* mean, float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M,
+                                         int64_t D, const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_mlp_quickgelu_recompute_e4m3(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode, uint16_t* g,
+                                            int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream);
+int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t, const uint8_t* dcode,
+                                         const uint16_t* g, const uint16_t* h, const float* x, const float* mean, const float* rstd,
+                                         const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* du, uint16_t* dh,
+                                         float* dw_proj, float* dw_fc, float* db_fc, float* dgamma, float* dbeta, float* dx_colsum,
+                                         int64_t M, int64_t D, void* workspace, size_t workspace_bytes, const vipant_fp8_plan* plan,
+                                         void* stream);
+
 /* K1 -- ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + contraction, cls token, positional table,
  * ln_pre.  x fp32 [b,C,T,F]; conv_w fp32 [Dw,Cw,ph,pw] (mean_channels != 0: the Cw stored channels are averaged, val.py:236-244);
  * scratch / saved: w_eff bf16 [Dw,kcols], patches bf16 [b*P,kcols], pe fp32 [b*P,Dw], tokens fp32 [b*S,Dw] (kcols =

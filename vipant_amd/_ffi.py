@@ -21,6 +21,11 @@ EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F3
 
 _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 
+class Fp8Plan(C.Structure):
+    """struct vipant_fp8_plan (include/vipant_hip.h): e4m3 weights + activation scratch of one fused block operator call."""
+    _fields_ = [("w_q", _p), ("w_scale", _p), ("w2_q", _p), ("w2_scale", _p), ("act_q", _p), ("act_scale", _p)]
+
+
 # name -> (restype, argtypes); mirrors include/vipant_hip.h one to one
 PROTOTYPES = {
     "vipant_last_error": (C.c_char_p, []),
@@ -61,6 +66,13 @@ PROTOTYPES = {
     # fused operator set (vipant_amd/csrc/block.hip)
     "vipant_block_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_ln_qkv_fwd": (_i32, [_p] * 11 + [_i64, _i64, _p]),
+    "vipant_ln_qkv_fwd_e4m3": (_i32, [_p] * 11 + [_i64, _i64, _p, _p]),
+    "vipant_ln_qkv_bwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p, _p]),
+    "vipant_gemm_bias_residual_fwd_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _p]),
+    "vipant_gemm_bias_residual_bwd_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _sz, _p, _p]),
+    "vipant_ln_mlp_quickgelu_fwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _p]),
+    "vipant_mlp_quickgelu_recompute_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _p, _p]),
+    "vipant_ln_mlp_quickgelu_bwd_e4m3": (_i32, [_p] * 20 + [_i64, _i64, _p, _sz, _p, _p]),
     "vipant_ln_qkv_bwd": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p]),
     "vipant_gemm_bias_residual_fwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p]),
     "vipant_gemm_bias_residual_bwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _sz, _p]),

@@ -89,6 +89,9 @@ class Monitor(object):
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):
                     head.encoder.recompute_mlp = True
+        if cfg.running.get("fp8_gemm", False):      # BASELINE.json configs[4]: e4m3 operands in the audio tower's NT contractions
+            if model.audio_head is not None and hasattr(model.audio_head, "encoder"):
+                model.audio_head.encoder.fp8 = True
         self.model.train(not cfg.eval)
         self.build_optimizer(tunable_params)
 

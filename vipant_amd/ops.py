@@ -9,6 +9,7 @@ The residual stream and its gradient are fp32; every MFMA operand is bf16 (fp32 
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -246,19 +247,44 @@ class _WeightCaster:
              self.C.data_ptr(), self.starts.data_ptr(), self.n, self.total, _stream())
         return self.wb, self.wt
 
+    def refresh_e4m3(self):
+        """Row-quantised e4m3 copies of the bf16 W and W^T just refreshed: [(bytes, row scales)] per matrix, both orientations
+        (the forward contractions read W rows, the input-gradient ones W^T rows)."""
+        if not hasattr(self, "wq"):
+            dev = self.wb[0].device
+            self.wq = [(torch.empty(t.shape, dtype=torch.uint8, device=dev), torch.empty((t.shape[0],), dtype=torch.uint8, device=dev))
+                       for t in self.wb]
+            self.wtq = [(torch.empty(t.shape, dtype=torch.uint8, device=dev), torch.empty((t.shape[0],), dtype=torch.uint8, device=dev))
+                        for t in self.wt]
+        for src, (q, sc) in zip(self.wb + self.wt, self.wq + self.wtq):
+            quant_e4m3(src, q, sc)
+        return self.wq, self.wtq
+
 
 _casters: Dict[tuple, _WeightCaster] = {}
 
 
-def cast_weights(weights: Sequence[torch.Tensor]):
-    """(list of bf16 W, list of bf16 W^T) for the trainable matrices of a tower, one launch."""
+def cast_weights(weights: Sequence[torch.Tensor], e4m3: bool = False):
+    """(list of bf16 W, list of bf16 W^T) for the trainable matrices of a tower, one launch; with `e4m3` also their row-quantised
+    e4m3 forms (lists of (bytes, row scales))."""
     key = tuple(w.data_ptr() for w in weights)
     c = _casters.get(key)
     if c is None:
         while len(_casters) >= 16:
             _casters.pop(next(iter(_casters)))
         c = _casters[key] = _WeightCaster([w.detach() for w in weights])
-    return c.refresh()
+    wb, wt = c.refresh()
+    if e4m3:
+        return (wb, wt) + tuple(c.refresh_e4m3())
+    return wb, wt
+
+
+def fp8_plan(w=None, w2=None, act=None):
+    """struct vipant_fp8_plan for one fused-operator call: w / w2 = (bytes, row scales) of the operator's weights, act = (scratch
+    bytes [M, 4D], scratch row scales [M])."""
+    from ._ffi import Fp8Plan
+    return Fp8Plan(w[0].data_ptr(), w[1].data_ptr(), w2[0].data_ptr() if w2 else None, w2[1].data_ptr() if w2 else None,
+                   act[0].data_ptr(), act[1].data_ptr())
 
 
 _frozen_cache: Dict[tuple, tuple] = {}
@@ -363,7 +389,7 @@ class BackboneFn(torch.autograd.Function):
     vipant_gemm_bias_residual_*, vipant_ln_mlp_quickgelu_*."""
 
     @staticmethod
-    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, *params):
+    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, *params):
         _need(x, F32, "backbone.x")
         M, D = x.shape
         assert M == batch * S and len(params) % 12 == 0
@@ -388,14 +414,23 @@ class BackboneFn(torch.autograd.Function):
         if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
+        fp8 = bool(fp8) and train       # e4m3 operands in the NT contractions of a trainable tower (configs[4]); frozen towers: bf16
         if train:               # bf16 copies (W and W^T) of the 4 L weight matrices: one launch per step
-            wb_all, wt_all = cast_weights([params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)])
+            mats = [params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)]
+            if fp8:
+                wb_all, wt_all, wq_all, wtq_all = cast_weights(mats, e4m3=True)
+                act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev))
+            else:
+                wb_all, wt_all = cast_weights(mats)
         for l in range(L):
             ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
             if train:
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4]
                 wqkv_t, wo_t, wfc_t, wpr_t = wt_all[4 * l:4 * l + 4]
-                wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None))
+                wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None) +
+                           ((wq_all[4 * l:4 * l + 4], wtq_all[4 * l:4 * l + 4]) if fp8 else (None, None)))
+                if fp8:
+                    q_qkv, q_o, q_fc, q_pr = wq_all[4 * l:4 * l + 4]
                 h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
                 mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
                 if keep_mlp:
@@ -405,12 +440,14 @@ class BackboneFn(torch.autograd.Function):
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
             # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
             xs = new(D, F32) if y_prev is not None else None
-            call("vipant_ln_qkv_fwd", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
-                 bqkv.data_ptr(), h1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D, st)
+            call("vipant_ln_qkv_fwd_e4m3", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
+                 bqkv.data_ptr(), h1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D,
+                 C.byref(fp8_plan(q_qkv, None, act)) if fp8 else None, st)
             if xs is not None:
                 x = xs
             o, lse = mha_fwd(qkv, batch, S, H, causal)
-            call("vipant_gemm_bias_residual_fwd", o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(), M, D, D, st)
+            call("vipant_gemm_bias_residual_fwd_e4m3", o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(), M, D, D,
+                 C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
             # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
             x1 = new(D, F32)
             if "gemm_nt" in KERNEL_PROBE:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
@@ -419,9 +456,10 @@ class BackboneFn(torch.autograd.Function):
                 gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU_D8)
                 gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             else:
-                call("vipant_ln_mlp_quickgelu_fwd", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
+                call("vipant_ln_mlp_quickgelu_fwd_e4m3", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
                      wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
-                     rstd2.data_ptr(), u.data_ptr(), g.data_ptr(), y2.data_ptr(), M, D, st)
+                     rstd2.data_ptr(), u.data_ptr(), g.data_ptr(), y2.data_ptr(), M, D,
+                     C.byref(fp8_plan(q_fc, q_pr, act)) if fp8 else None, st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
@@ -431,13 +469,13 @@ class BackboneFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
-            ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp))
+            ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8)
             ctx.grad_sync = grad_sync
         return x
 
     @staticmethod
     def backward(ctx, dx_in):
-        batch, S, causal, L, H, recompute_mlp = ctx.meta
+        batch, S, causal, L, H, recompute_mlp, fp8 = ctx.meta
         tensors = ctx.saved_tensors
         ns = 11 if recompute_mlp else 13
         saved, params = tensors[:ns * L], tensors[ns * L:]
@@ -455,6 +493,7 @@ class BackboneFn(torch.autograd.Function):
             dx = None
             dx_b = cast_bf16_flat(dx_in.contiguous())
         ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
+        act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev)) if fp8 else None
         du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
         dh = torch.empty((M, D), dtype=BF16, device=dev)
         do = torch.empty((M, D), dtype=BF16, device=dev)
@@ -467,29 +506,31 @@ class BackboneFn(torch.autograd.Function):
         for l in reversed(range(L)):
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             ln1w, _, _, _, _, _, ln2w, _, _, bfc, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
-            wqkv_t, wo_t, wfc_t, wpr_t, wfc_b = ctx.wts[l]
+            wqkv_t, wo_t, wfc_t, wpr_t, wfc_b, wq4, wtq4 = ctx.wts[l]
             (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
             lg_below = _LayerGrads([p.shape for p in params[12 * (l - 1):12 * l]], dev) if l > 0 else None
             if recompute_mlp:
-                call("vipant_mlp_quickgelu_recompute", h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(), g.data_ptr(),
-                     M, D, st)
+                call("vipant_mlp_quickgelu_recompute_e4m3", h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(), g.data_ptr(),
+                     M, D, C.byref(fp8_plan(wq4[2], None, act)) if fp8 else None, st)
             else:
                 u, g = saved[ns * l + 11:ns * l + 13]
             # MLP half: c_proj^T + QuickGELU', c_fc^T, both weight gradients, ln_2 backward (+ residual gradient);
             # the produced stream gradient is also d(out_proj output): its column sum is d out_proj.bias
-            call("vipant_ln_mlp_quickgelu_bwd", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(), g.data_ptr(),
+            call("vipant_ln_mlp_quickgelu_bwd_e4m3", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(), g.data_ptr(),
                  h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
-                 d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(), st)
+                 d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act)) if fp8 else None, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
-            call("vipant_gemm_bias_residual_bwd", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
-                 M, D, D, ws.data_ptr(), ws.numel(), st)
+            call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
+                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act)) if fp8 else None, st)
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
-            call("vipant_ln_qkv_bwd", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
+            call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
-                 lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(), st)
+                 lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
+                 C.byref(fp8_plan(wtq4[0], None, act)) if fp8 else None, st)
             del dqkv
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
@@ -501,8 +542,8 @@ class BackboneFn(torch.autograd.Function):
         if dx is None and need[0]:
             dx = torch.empty((M, D), dtype=F32, device=dev)
             call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
-        out_grads = [gr if need[6 + i] else None for i, gr in enumerate(grads)]
-        return (dx if need[0] else None, None, None, None, None, None, *out_grads)
+        out_grads = [gr if need[7 + i] else None for i, gr in enumerate(grads)]
+        return (dx if need[0] else None, None, None, None, None, None, None, *out_grads)
 
 
 # ---------------------------------------------------------------------------------- read-out
