@@ -377,8 +377,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     const int frow = lane & 15, fq = lane >> 4, fs = (lane >> 1) & 7;
 
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    const int ntiles = ntm * ntn;
+    // experiment (VAR 7 / 8): column-grouped walk -- the XCDs split into two column groups (each keeps HALF of the weight matrix,
+    // meant to stay in its 4 MiB L2) times four row quarters; a workgroup's sequence number then maps to (panel, column) inside
+    // its XCD's share.  Needs the full grid of 256 and an even number of column tiles.
+    constexpr bool GROUPED = VAR == 7 || VAR == 8;
     const int G = gridDim.x;                                   // multiple of 8, <= ntiles rounded up
+    const int cg = ntn / 2, ppx = (ntm + 3) / 4;
+    const int ntiles = GROUPED ? ((ppx * cg + 31) / 32) * 256 : ntm * ntn;
     const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
     const int nk = p.K / (ES == 2 ? BK : 2 * BK);
@@ -411,8 +416,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     struct TileDesc { const char* a; const char* b; uint32_t abytes, bbytes; int m0, n0; };
     auto describe = [&](int tile) {
         TileDesc d;
-        if (tile < ntiles) {
-            const int tm = tile / ntn, tn = tile % ntn;
+        int tm = tile / ntn, tn = tile % ntn;
+        bool valid = tile < ntiles;
+        if (GROUPED) {
+            const int xcd = (tile & 255) >> 5, sq = (tile & 31) + 32 * (tile >> 8);
+            const int pl = sq / cg;
+            tm = (xcd & 3) * ppx + pl; tn = (xcd >> 2) * cg + sq % cg;
+            valid = valid && pl < ppx && tm < ntm;
+        }
+        if (valid) {
             d.m0 = tm * BM; d.n0 = tn * BN;
             const int64_t a_bytes = ((int64_t)(p.M - d.m0) * p.lda - (p.lda - p.K)) * ES;
             const int64_t b_bytes = ((int64_t)(p.N - d.n0) * p.ldb - (p.ldb - p.K)) * ES;
@@ -565,8 +577,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 char* const da = ldsA + (stage ^ 1) * PP_A_STAGE;
                 char* const db = ldsB + (grp == 0 ? slot1 : slot2) * PP_B_SLOT;
                 auto dma_piece = [&](int i) {      // piece i of this wave's 8: 4 of A, then 4 of B
-                    if (i < 4) lds_dma16(ra, da + i * 1024, voffA[i & 1], ka + waveA + (i >> 1) * pairA);
-                    else lds_dma16(rb, db + (i - 4) * 1024, voffB[i & 1], kb + waveB + ((i - 4) >> 1) * pairB);
+                    if (i < 4) {
+                        if (VAR == 4 || VAR == 6 || VAR == 7)       // experiment: non-temporal hint on the streamed operand
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_AS void*)(da + i * 1024), 16, voffA[i & 1],
+                                                                     ka + waveA + (i >> 1) * pairA, 0, 2);
+                        else lds_dma16(ra, da + i * 1024, voffA[i & 1], ka + waveA + (i >> 1) * pairA);
+                    } else {
+                        if (VAR == 5 || VAR == 6)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_AS void*)(db + (i - 4) * 1024), 16, voffB[i & 1],
+                                                                     kb + waveB + ((i - 4) >> 1) * pairB, 0, 2);
+                        else lds_dma16(rb, db + (i - 4) * 1024, voffB[i & 1], kb + waveB + ((i - 4) >> 1) * pairB);
+                    }
                 };
                 if (VAR == 1) {                    // fragment reads first: their LDS round trip runs under the DMA issue
                     frag_head(0, stage, slot);
@@ -759,6 +780,14 @@ int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     if (p.dbg & 32) return launch_pp_variant<EPI, 1>(p, stream);
     if (p.dbg & 64) return launch_pp_variant<EPI, 2>(p, stream);
     if (p.dbg & 128) return launch_pp_variant<EPI, 3>(p, stream);
+    if ((p.dbg & 768) == 256) return launch_pp_variant<EPI, 4>(p, stream);
+    if ((p.dbg & 768) == 512) return launch_pp_variant<EPI, 5>(p, stream);
+    if ((p.dbg & 768) == 768) return launch_pp_variant<EPI, 6>(p, stream);
+    const bool groupable = ceil_div(p.N, BN) % 2 == 0 && ceil_div(p.M, BM) * ceil_div(p.N, BN) >= 256;
+    if ((p.dbg & 1024) && groupable) return launch_pp_variant<EPI, 7>(p, stream);
+    // the column-grouped walk is the default of the c_fc launch (853 vs 870-881 us, step -0.27 ms in-box; the QuickGELU' launch of
+    // the same shape does not move: profiles/r2_gemm_experiments.md section 9); bit 11 forces it everywhere, bit 12 turns it off
+    if (groupable && !(p.dbg & 4096) && (EPI == VIPANT_EPI_QUICKGELU_D8 || (p.dbg & 2048))) return launch_pp_variant<EPI, 8>(p, stream);
     return launch_pp_variant<EPI, 0>(p, stream);
 }
 
