@@ -19,9 +19,9 @@ from collections import defaultdict
 
 M, D = 512 * 316, 768
 KERNELS = {      # substring of the rocprofv3 kernel name -> (label, algorithmic bytes per launch)
-    "gemm_nt_pp_kernel<6, 0>": (f"gemm_nt_pp_kernel<6, 0> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
-    "gemm_nt_pp_kernel<7, 0>": (f"gemm_nt_pp_kernel<7, 0> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
-    "ln_bwd_kernelILi3ELb0": (f"ln_bwd_kernel<3> M={M} D={D}", 16 * M * D),
+    "gemm_nt_pp_kernel<6, 8, 2>": (f"gemm_nt_pp_kernel<6, 8, 2> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
+    "gemm_nt_pp_kernel<7, 0, 2>": (f"gemm_nt_pp_kernel<7, 0, 2> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
+    "ln_bwd_kernelILi3ELb0": (f"ln_bwd_kernel<3> M={M} D={D}", 10 * M * D),
     "mha_fwd_kernel<20": ("mha_fwd_kernel<20> b=512 S=316 H=12", 2 * M * 3 * D + 2 * M * D + 4 * 512 * 12 * 316),
 }
 
