@@ -354,6 +354,144 @@ constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+// The tile epilogue of the ping-pong kernels: 4 rounds of 32 rows of the group's 128 x 256 accumulator block staged through 16 KiB
+// of LDS (`stg`, free for this group at this point of its stream) and written out row-contiguous, with the epilogue arithmetic.
+template <int EPI>
+__device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], const f32x4 (&bv)[4], char* stg, char* stg_hi,
+                                            int m0, int n0, int grp, int wl, int frow, int fq, int tid) {
+    // rows 0-15 of a round are staged at `stg`, rows 16-31 at `stg_hi` (the ring kernel has two free 8-KiB pieces, not one of 16)
+    stg_hi -= 16 * 512;
+    auto sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    const int tl = tid & 255;
+    constexpr bool GELU_OUT = EPI == VIPANT_EPI_QUICKGELU || EPI == VIPANT_EPI_QUICKGELU_D8;
+    constexpr bool GELU_IN = EPI == VIPANT_EPI_DQUICKGELU || EPI == VIPANT_EPI_DQUICKGELU_D8;
+    constexpr bool D8 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
+    // QuickGELU' inputs of the next round (bf16 pre-activations, or their 8-bit derivative codes), loaded one round ahead
+    bf16x8 un[4];
+    u32x2 cn[4];
+    auto load_aux = [&](int r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = t * 256 + tl;
+            const int R = idx >> 5, ch = idx & 31;
+            const int m = m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = n0 + ch * 8;
+            const bool ok = m < p.M && n < p.N;
+            if (D8) cn[t] = ok ? *(const u32x2*)((const uint8_t*)p.aux + (int64_t)m * p.ldc + n) : u32x2{0u, 0u};
+            else un[t] = ok ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
+        }
+    };
+    if (GELU_IN) load_aux(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = r * 2 + ii;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int colbyte = wl * 128 + j * 32 + fq * 8;
+                *(bf16x4*)((ii ? stg_hi : stg) + (ii * 16 + frow) * 512 + (((colbyte >> 4) ^ frow) << 4) + (colbyte & 8)) =
+                    f32x4_to_bf16x4(acc[i][j] + bv[j]);
+            }
+        }
+        sync();
+        bf16x8 u8[4];
+        u32x2 c8[4];
+        if (GELU_IN) {      // this round's inputs arrived during the previous round
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { u8[t] = un[t]; c8[t] = cn[t]; }
+            if (r + 1 < 4) load_aux(r + 1);
+        }
+        if (EPI == VIPANT_EPI_QUICKGELU_D8 && (p.N & 15) == 0 && (p.ldc & 15) == 0) {
+            // a thread takes 16 consecutive columns, so that the code leaves as one 16-B store per thread (the store path
+            // is bound by instructions as much as by bytes: 6 instead of 8 store instructions per thread and round)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = t * 256 + tl;
+                const int R = idx >> 4, cp = idx & 15;
+                const int m = m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = n0 + cp * 16;
+                if (m < p.M && n < p.N && !(p.dbg & 1)) {
+                    const int64_t o = (int64_t)m * p.ldc + n;
+                    uint32_t cw[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bf16x8 v = *(const bf16x8*)((R & 16 ? stg_hi : stg) + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
+                        bf16x8 g;
+                        cw[h * 2] = cw[h * 2 + 1] = 0u;
+                        // two elements per instruction (v_pk_mul / v_pk_add / v_pk_fma): this epilogue is bound by its own
+                        // arithmetic as much as by its stores.  code = 212.5 (sg + 1.702 ge (1 - sg)) + 21.25, constants folded.
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 u = f32x2{(float)v[e], (float)v[e + 1]};
+                            const f32x2 a = u * -2.4554669595930157f;
+                            const f32x2 b = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+                            const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+                            const f32x2 ge = u * sg;
+                            const f32x2 c = (ge * 361.675f) * (1.0f - sg) + (sg * 212.5f + 21.25f);
+                            g[e] = (bf16_t)ge[0];
+                            g[e + 1] = (bf16_t)ge[1];
+                            uint32_t& w = cw[h * 2 + (e >> 2)];
+                            w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
+                            w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
+                        }
+                        *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
+                    }
+                    *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
+                }
+            }
+            sync();
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = t * 256 + tl;
+            const int R = idx >> 5, ch = idx & 31;
+            const int m = m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = n0 + ch * 8;
+            if (m < p.M && n < p.N && !(p.dbg & 1)) {
+                const bf16x8 v = *(const bf16x8*)((R & 16 ? stg_hi : stg) + R * 512 + ((ch ^ (R & 15)) << 4));
+                const int64_t o = (int64_t)m * p.ldc + n;
+                if (EPI == VIPANT_EPI_BF16) {
+                    *(bf16x8*)((bf16_t*)p.C + o) = v;
+                } else if (GELU_OUT) {
+                    bf16x8 g;
+                    uint32_t code[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float u = (float)v[e];
+                        const float sg = quickgelu_gate(u);
+                        g[e] = (bf16_t)(u * sg);
+                        code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
+                    }
+                    if (D8)
+                        *(u32x2*)((uint8_t*)p.aux + o) = u32x2{code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24,
+                                                               code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
+                    else
+                        *(bf16x8*)((bf16_t*)p.aux + o) = v;
+                    *(bf16x8*)((bf16_t*)p.C + o) = g;
+                } else {  // QuickGELU'
+                    bf16x8 d;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float dg;
+                        if (D8) {
+                            dg = gelu_decode((c8[t][e >> 2] >> ((e & 3) * 8)) & 255u);
+                        } else {
+                            const float u = (float)u8[t][e];
+                            const float sg = quickgelu_gate(u);
+                            dg = sg * (1.0f + 1.702f * u * (1.0f - sg));
+                        }
+                        d[e] = (bf16_t)((float)v[e] * dg);
+                    }
+                    *(bf16x8*)((bf16_t*)p.C + o) = d;
+                }
+            }
+        }
+        sync();
+    }
+}
+
 // v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands.  Operand layout (tools/probes/mx_layout_probe.hip, mx_scale_probe.hip,
 // exact integer data on the MI355X): lane (r = lane & 15, q = lane >> 4) holds bytes k = 16 q .. 16 q + 15 of row r in dwords
 // 0-3 and k = 64 + 16 q .. in dwords 4-7 -- the two 16-byte fragments the bf16 loop reads for its k-steps 0 and 1 of a 128-byte
@@ -596,9 +734,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     for (int i = 0; i < 8; ++i) dma_piece(i);
                 } else if (VAR == 3) {             // spread: one piece behind each MFMA group of k-step 0
                     frag_head(0, stage, slot);
-                } else {                           // burst at the top of the K-tile
+                } else {                           // burst at the top of the K-tile (VAR 9, look-ahead probe: at its middle)
+                    if (VAR != 9) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dma_piece(i);
+                        for (int i = 0; i < 8; ++i) dma_piece(i);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (ES == 1) frag_head8(Int<0>{}, stage, slot); else
                     frag_head(0, stage, slot);
@@ -608,10 +748,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 if (VAR == 3) half_body(0, stage, dma_piece); else
                 half_body(0, stage, [](int) {});
                 if (VAR == 2) __builtin_amdgcn_s_setprio(0);
-                if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (grp == 1) {
+                    if (VAR == 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
                 sync();
-            }
-            {   // second interval: k-step 1
+                // second interval: k-step 1
+                if (VAR == 9) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dma_piece(i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (ES == 1) frag_head8(Int<1>{}, stage, slot); else
                 frag_head(1, stage, slot);
                 if (VAR == 2) __builtin_amdgcn_s_setprio(1);
@@ -627,131 +774,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         }
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
-        const int tl = tid & 255;
-        constexpr bool GELU_OUT = EPI == VIPANT_EPI_QUICKGELU || EPI == VIPANT_EPI_QUICKGELU_D8;
-        constexpr bool GELU_IN = EPI == VIPANT_EPI_DQUICKGELU || EPI == VIPANT_EPI_DQUICKGELU_D8;
-        constexpr bool D8 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
-        // QuickGELU' inputs of the next round (bf16 pre-activations, or their 8-bit derivative codes), loaded one round ahead
-        bf16x8 un[4];
-        u32x2 cn[4];
-        auto load_aux = [&](int r) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int idx = t * 256 + tl;
-                const int R = idx >> 5, ch = idx & 31;
-                const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + ch * 8;
-                const bool ok = m < p.M && n < p.N;
-                if (D8) cn[t] = ok ? *(const u32x2*)((const uint8_t*)p.aux + (int64_t)m * p.ldc + n) : u32x2{0u, 0u};
-                else un[t] = ok ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
-            }
-        };
-        if (GELU_IN) load_aux(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = r * 2 + ii;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int colbyte = wl * 128 + j * 32 + fq * 8;
-                    *(bf16x4*)(stg + (ii * 16 + frow) * 512 + (((colbyte >> 4) ^ frow) << 4) + (colbyte & 8)) =
-                        f32x4_to_bf16x4(acc[i][j] + bv[j]);
-                }
-            }
-            sync();
-            bf16x8 u8[4];
-            u32x2 c8[4];
-            if (GELU_IN) {      // this round's inputs arrived during the previous round
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { u8[t] = un[t]; c8[t] = cn[t]; }
-                if (r + 1 < 4) load_aux(r + 1);
-            }
-            if (EPI == VIPANT_EPI_QUICKGELU_D8 && (p.N & 15) == 0 && (p.ldc & 15) == 0) {
-                // a thread takes 16 consecutive columns, so that the code leaves as one 16-B store per thread (the store path
-                // is bound by instructions as much as by bytes: 6 instead of 8 store instructions per thread and round)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int idx = t * 256 + tl;
-                    const int R = idx >> 4, cp = idx & 15;
-                    const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + cp * 16;
-                    if (m < p.M && n < p.N && !(p.dbg & 1)) {
-                        const int64_t o = (int64_t)m * p.ldc + n;
-                        uint32_t cw[4];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const bf16x8 v = *(const bf16x8*)(stg + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
-                            bf16x8 g;
-                            cw[h * 2] = cw[h * 2 + 1] = 0u;
-                            // two elements per instruction (v_pk_mul / v_pk_add / v_pk_fma): this epilogue is bound by its own
-                            // arithmetic as much as by its stores.  code = 212.5 (sg + 1.702 ge (1 - sg)) + 21.25, constants folded.
-#pragma unroll
-                            for (int e = 0; e < 8; e += 2) {
-                                const f32x2 u = f32x2{(float)v[e], (float)v[e + 1]};
-                                const f32x2 a = u * -2.4554669595930157f;
-                                const f32x2 b = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
-                                const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
-                                const f32x2 ge = u * sg;
-                                const f32x2 c = (ge * 361.675f) * (1.0f - sg) + (sg * 212.5f + 21.25f);
-                                g[e] = (bf16_t)ge[0];
-                                g[e + 1] = (bf16_t)ge[1];
-                                uint32_t& w = cw[h * 2 + (e >> 2)];
-                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
-                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
-                            }
-                            *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
-                        }
-                        *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
-                    }
-                }
-                sync();
-                continue;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int idx = t * 256 + tl;
-                const int R = idx >> 5, ch = idx & 31;
-                const int m = cur.m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = cur.n0 + ch * 8;
-                if (m < p.M && n < p.N && !(p.dbg & 1)) {
-                    const bf16x8 v = *(const bf16x8*)(stg + R * 512 + ((ch ^ (R & 15)) << 4));
-                    const int64_t o = (int64_t)m * p.ldc + n;
-                    if (EPI == VIPANT_EPI_BF16) {
-                        *(bf16x8*)((bf16_t*)p.C + o) = v;
-                    } else if (GELU_OUT) {
-                        bf16x8 g;
-                        uint32_t code[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float u = (float)v[e];
-                            const float sg = quickgelu_gate(u);
-                            g[e] = (bf16_t)(u * sg);
-                            code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
-                        }
-                        if (D8)
-                            *(u32x2*)((uint8_t*)p.aux + o) = u32x2{code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24,
-                                                                   code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
-                        else
-                            *(bf16x8*)((bf16_t*)p.aux + o) = v;
-                        *(bf16x8*)((bf16_t*)p.C + o) = g;
-                    } else {  // QuickGELU'
-                        bf16x8 d;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float dg;
-                            if (D8) {
-                                dg = gelu_decode((c8[t][e >> 2] >> ((e & 3) * 8)) & 255u);
-                            } else {
-                                const float u = (float)u8[t][e];
-                                const float sg = quickgelu_gate(u);
-                                dg = sg * (1.0f + 1.702f * u * (1.0f - sg));
-                            }
-                            d[e] = (bf16_t)((float)v[e] * dg);
-                        }
-                        *(bf16x8*)((bf16_t*)p.C + o) = d;
-                    }
-                }
-            }
-            sync();
-        }
+        pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid);
         tile += G;
         cur = nxt;
         nxt = describe(tile + G);
@@ -775,6 +798,7 @@ int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
     return VIPANT_OK;
 }
 
+
 template <int EPI>
 int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     if (p.dbg & 32) return launch_pp_variant<EPI, 1>(p, stream);
@@ -783,6 +807,7 @@ int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     if ((p.dbg & 768) == 256) return launch_pp_variant<EPI, 4>(p, stream);
     if ((p.dbg & 768) == 512) return launch_pp_variant<EPI, 5>(p, stream);
     if ((p.dbg & 768) == 768) return launch_pp_variant<EPI, 6>(p, stream);
+    if (p.dbg & 8192) return launch_pp_variant<EPI, 9>(p, stream);
     const bool groupable = ceil_div(p.N, BN) % 2 == 0 && ceil_div(p.M, BM) * ceil_div(p.N, BN) >= 256;
     if ((p.dbg & 1024) && groupable) return launch_pp_variant<EPI, 7>(p, stream);
     // the column-grouped walk is the default of the c_fc launch (853 vs 870-881 us, step -0.27 ms in-box; the QuickGELU' launch of
