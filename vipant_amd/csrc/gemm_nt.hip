@@ -584,6 +584,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         for (int i = 0; i < 4; ++i)
             lds_dma16(rs, ldsB + slot * PP_B_SLOT + i * 1024, voffB[i & 1], koff + waveB + (i >> 1) * pairB);
     };
+    // DEEP schedule (VAR 10; intervals by row halves, B fragments kept in registers): a wave owns 16 rows in EACH 64-row half of
+    // its group's A stage (two 1-KiB pieces per half), so that a half can be refilled as soon as its interval is over
+    constexpr bool DEEP = VAR == 10;
+    char* const ldsA2 = smem + grp * (2 * PP_A_STAGE) + wl * 2048;
+    const uint32_t waveA2 = (uint32_t)((grp * 128 + wl * 16) * p.lda * ES), halfA = (uint32_t)(64 * p.lda * ES);
+    auto fill_a_half = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, int half, uint32_t koff) {
+        lds_dma16(rs, ldsA2 + stage * PP_A_STAGE + half * 8192, voffA[0], koff + waveA2 + half * halfA);
+        lds_dma16(rs, ldsA2 + stage * PP_A_STAGE + half * 8192 + 1024, voffA[1], koff + waveA2 + half * halfA);
+    };
 
     f32x4 acc[8][4];
     // Fragment pipeline of one 32-deep k-step (= one barrier interval): B fragments up front, A fragments two MFMA groups
@@ -676,6 +685,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         load_scales(cur, sav, sbv);
         asm volatile("" : "+v"(sav[0]), "+v"(sav[1]), "+v"(sbv));             // awaited before any DMA is in flight
     }
+    if (DEEP) {     // K-tile 0 (A, B), K-tile 1 (B; A rows 0-63): what the steady state would have issued before K-tile 0
+        const bool wrap = nk < 2;
+        const __amdgpu_buffer_rsrc_t ra1 = wrap ? make_rsrc(nxt.a, nxt.abytes) : make_rsrc(cur.a, cur.abytes);
+        const __amdgpu_buffer_rsrc_t rb1 = wrap ? make_rsrc(nxt.b, nxt.bbytes) : make_rsrc(cur.b, cur.bbytes);
+        fill_a_half(make_rsrc(cur.a, cur.abytes), 0, 0, 0);
+        fill_a_half(make_rsrc(cur.a, cur.abytes), 0, 1, 0);
+        fill_b(make_rsrc(cur.b, cur.bbytes), 0, 0);
+        fill_b(rb1, 1, wrap ? 0u : (uint32_t)(BK * 2));
+        fill_a_half(ra1, 1, 0, wrap ? 0u : (uint32_t)(BK * 2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     // prologue: K-tile 0 of the first tile (and, for group 1, its B rows of K-tile 1)
     fill_a(make_rsrc(cur.a, cur.abytes), 0, 0);
     fill_b(make_rsrc(cur.b, cur.bbytes), 0, 0);
@@ -685,6 +705,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the lag: group 1 runs one barrier interval behind group 0
@@ -705,6 +726,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
                 if (ES == 1) asm volatile("" : "+v"(sav_n[0]), "+v"(sav_n[1]), "+v"(sbv_n));
             }
+            if (DEEP) {
+                // interval 0 (row tiles 0-3): B rows of K-tile k+2 (its slot was last read one interval ago by the lagging group),
+                // A rows 64-127 of K-tile k+1 (their half-stage was consumed in the previous interval); interval 1 (row tiles 4-7):
+                // A rows 0-63 of K-tile k+2.  Every piece has three intervals (B of group 0: four) to land; at most the eight most
+                // recent pieces may be outstanding at either barrier.
+                const bool w1 = k + 1 >= nk, w2 = k + 2 >= nk;
+                const uint32_t k1 = (uint32_t)((w1 ? k + 1 - nk : k + 1) * BK * 2), k2 = (uint32_t)((w2 ? k + 2 - nk : k + 2) * BK * 2);
+                fill_b(make_rsrc(w2 ? nxt.b : cur.b, w2 ? nxt.bbytes : cur.bbytes), slot2, k2);
+                fill_a_half(make_rsrc(w1 ? nxt.a : cur.a, w1 ? nxt.abytes : cur.abytes), stage ^ 1, 1, k1);
+                __builtin_amdgcn_sched_barrier(0);
+                frag_head8(Int<0>{}, stage, slot);
+                half_body8(Int<0>{}, stage);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                sync();
+                fill_a_half(make_rsrc(w2 ? nxt.a : cur.a, w2 ? nxt.abytes : cur.abytes), stage, 0, k2);
+                __builtin_amdgcn_sched_barrier(0);
+                frag_head8(Int<1>{}, stage, slot);
+                half_body8(Int<1>{}, stage);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                sync();
+            } else
             {   // first interval: DMA of the stream's next K-tile(s), k-step 0
                 const bool w1 = k + 1 >= nk, w2 = k + 2 >= nk;
                 const bool wb = grp == 0 ? w1 : w2;
@@ -774,6 +816,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         }
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
+        if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
         pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid);
         tile += G;
         cur = nxt;
@@ -908,10 +951,14 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
                    "gemm_nt_e4m3: operands must be 16-byte aligned");
     VIPANT_REQUIRE(sa != nullptr && sb != nullptr, VIPANT_EBADSHAPE, "gemm_nt_e4m3: the row scales of both operands are required");
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
+    static const int fp8_dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
     GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, sa, sb};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
-        case VIPANT_EPI_BF16: return launch_pp_variant<VIPANT_EPI_BF16, 0, 1>(p, s);
+        case VIPANT_EPI_BF16:
+            // the deep look-ahead schedule (VAR 10): -2..-4 % at K >= 3072, neutral at K <= 1024; bit 15 of VIPANT_GEMM_VARIANT: off
+            if (!(fp8_dbg & 32768)) return launch_pp_variant<VIPANT_EPI_BF16, 10, 1>(p, s);
+            return launch_pp_variant<VIPANT_EPI_BF16, 0, 1>(p, s);
         case VIPANT_EPI_QUICKGELU_D8:
         case VIPANT_EPI_DQUICKGELU_D8:
             VIPANT_REQUIRE(aux != nullptr && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
