@@ -343,18 +343,22 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict_
 
 // bf16 rows -> e4m3 (OCP e4m3fn) rows with ONE power-of-two scale per row (BASELINE.json configs[4]: fp8 operands of the block
 // contractions): e = the smallest exponent with amax / 2^e <= 448, q = rne(x / 2^e), scale byte = e + 127 (E8M0, the form the
-// block-scale operand of v_mfma_scale_f32_16x16x128_f8f6f4 takes).  One wave per row; the row is read twice (second pass from L2).
+// block-scale operand of v_mfma_scale_f32_16x16x128_f8f6f4 takes).  One wave per row, the row held in registers between finding its maximum and converting it.
+template <int NV>      // NV = ceil(K / 512): 16-byte chunks per lane; the row stays in registers between the two passes over it
 __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
                                                               int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const bf16_t* xr = x + row * ldx;
+    bf16x8 v[NV];
     float amax = 0.f;
-    for (int c = lane * 8; c < K; c += 512) {
-        const bf16x8 v = *(const bf16x8*)(xr + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 8 + i * 512;
+        v[i] = c < K ? *(const bf16x8*)(xr + c) : bf16x8{};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
@@ -367,14 +371,17 @@ __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __re
     const float inv = __uint_as_float((uint32_t)(127 - e) << 23);              // 2^-e
     if (lane == 0) scale[row] = (uint8_t)(e + 127);
     uint8_t* qr = q + row * ldq;
-    for (int c = lane * 8; c < K; c += 512) {
-        const bf16x8 v = *(const bf16x8*)(xr + c);
-        int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[0] * inv, (float)v[1] * inv, w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[2] * inv, (float)v[3] * inv, w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[4] * inv, (float)v[5] * inv, w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[6] * inv, (float)v[7] * inv, w1, true);
-        *(int2*)(qr + c) = int2{w0, w1};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < K) {
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][0] * inv, (float)v[i][1] * inv, w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][2] * inv, (float)v[i][3] * inv, w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][4] * inv, (float)v[i][5] * inv, w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][6] * inv, (float)v[i][7] * inv, w1, true);
+            *(int2*)(qr + c) = int2{w0, w1};
+        }
     }
 }
 
@@ -382,12 +389,22 @@ __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __re
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,
                                           int64_t K, void* stream) {
-    VIPANT_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= (1 << 20), VIPANT_EBADSHAPE, "quant_e4m3_rows: need K %% 8 == 0 (M=%ld K=%ld)",
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= 4096, VIPANT_EBADSHAPE, "quant_e4m3_rows: need K %% 8 == 0 and K <= 4096 (M=%ld K=%ld)",
                    (long)M, (long)K);
     VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0, VIPANT_EALIGN,
                    "quant_e4m3_rows: misaligned rows");
-    hipLaunchKernelGGL(quant_e4m3_rows_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       q, ldq, scale, M, (int)K);
+    const dim3 grid((unsigned)ceil_div(M, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define VIPANT_QUANT_CASE(NV) \
+    case NV: hipLaunchKernelGGL(quant_e4m3_rows_kernel<NV>, grid, block, 0, st, (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K); break;
+    switch ((int)ceil_div(K, 512)) {
+        VIPANT_QUANT_CASE(1) VIPANT_QUANT_CASE(2) VIPANT_QUANT_CASE(3) VIPANT_QUANT_CASE(4) VIPANT_QUANT_CASE(5) VIPANT_QUANT_CASE(6)
+        VIPANT_QUANT_CASE(7) VIPANT_QUANT_CASE(8)
+        default:
+            vipant_set_error("quant_e4m3_rows: rows longer than 4096 elements are not built (K=%ld)", (long)K);
+            return VIPANT_EBADSHAPE;
+    }
+#undef VIPANT_QUANT_CASE
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
