@@ -273,7 +273,21 @@ typedef struct vipant_fp8_plan {
     const uint8_t* w2_scale;
     uint8_t* act_q;
     uint8_t* act_scale;
+    /* backward operators, optional (both or neither): bytes [M, D] + [M] that accompany the bf16 stream gradient `dx_bf16` between
+     * operators.  On entry they hold the quantised form of the incoming gradient (the operator's first contraction then skips its
+     * quantisation pass); an operator that produces a new stream gradient (its LayerNorm backward) writes the new one's there. */
+    uint8_t* dy_q;
+    uint8_t* dy_scale;
 } vipant_fp8_plan;
+/* LayerNorm with the row quantisation of its bf16 output fused (the row is in registers anyway): q bytes [M, D] / qscale bytes [M]
+ * = vipant_quant_e4m3_rows of y resp. dx_bf16, bit for bit; both NULL: exactly vipant_layernorm_fwd / vipant_layernorm_bwd. */
+int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y, float* y_f32,
+                                  float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add, float* sum_out, uint8_t* q,
+                                  uint8_t* qscale, void* stream);
+int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const float* x, int64_t ldx, const float* mean, const float* rstd,
+                                  const float* gamma, const void* dres, float* dx_f32, int64_t lddx, uint16_t* dx_bf16,
+                                  float* dgamma, float* dbeta, float* dx_colsum, int32_t accumulate, int64_t M, int64_t D,
+                                  void* workspace, size_t workspace_bytes, uint8_t* q, uint8_t* qscale, void* stream);
 int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
                                const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd, uint16_t* qkv,
                                int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream);

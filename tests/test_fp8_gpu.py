@@ -141,3 +141,39 @@ def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
     assert rel(y1, y0) < 8e-2, rel(y1, y0)
     assert rel(dx1, dx0) < 0.1, rel(dx1, dx0)
     assert worst[0] < 0.2, worst
+
+
+@pytest.mark.parametrize("D", [768, 1024])
+def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
+    """vipant_layernorm_{fwd,bwd}_e4m3: the bytes and row scales written beside the bf16 output are exactly what
+    vipant_quant_e4m3_rows makes of that output (so fusing the pass changes nothing downstream)."""
+    M = 1000
+    x = rnd(M, D, seed=31) * torch.exp2(torch.randint(-4, 5, (M, 1), device=DEV).float())
+    add = rnd(M, D, seed=32).to(torch.bfloat16)
+    gamma, beta = rnd(D, seed=33), rnd(D, seed=34)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    xs = torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    q = torch.empty(M, D, dtype=torch.uint8, device=DEV)
+    qs = torch.empty(M, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ops.call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, mean.data_ptr(),
+             rstd.data_ptr(), M, D, add.data_ptr(), xs.data_ptr(), q.data_ptr(), qs.data_ptr(), st)
+    q_ref, s_ref = ops.quant_e4m3(y)
+    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
+    y_plain = ops.layernorm_fwd(x, gamma, beta, add=add, want_sum=True)[0]
+    assert torch.equal(y, y_plain)
+    # backward, bf16 gradient stream in place
+    dy = rnd(M, D, seed=35).to(torch.bfloat16)
+    dxb = rnd(M, D, seed=36).to(torch.bfloat16)
+    dxb2 = dxb.clone()
+    dg, db, cs = (torch.empty(D, device=DEV) for _ in range(3))
+    ws = ops.scratch("ln_bwd", ops.query("vipant_layernorm_bwd_workspace_bytes", M, D), x.device)
+    ops.call("vipant_layernorm_bwd_e4m3", dy.data_ptr(), 2, xs.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+             dxb.data_ptr(), None, D, dxb.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(),
+             q.data_ptr(), qs.data_ptr(), st)
+    q_ref, s_ref = ops.quant_e4m3(dxb)
+    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
+    ops.call("vipant_layernorm_bwd", dy.data_ptr(), 2, xs.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+             dxb2.data_ptr(), None, D, dxb2.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(), st)
+    assert torch.equal(dxb, dxb2)

@@ -23,7 +23,8 @@ _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_siz
 
 class Fp8Plan(C.Structure):
     """struct vipant_fp8_plan (include/vipant_hip.h): e4m3 weights + activation scratch of one fused block operator call."""
-    _fields_ = [("w_q", _p), ("w_scale", _p), ("w2_q", _p), ("w2_scale", _p), ("act_q", _p), ("act_scale", _p)]
+    _fields_ = [("w_q", _p), ("w_scale", _p), ("w2_q", _p), ("w2_scale", _p), ("act_q", _p), ("act_scale", _p),
+                ("dy_q", _p), ("dy_scale", _p)]
 
 
 # name -> (restype, argtypes); mirrors include/vipant_hip.h one to one
@@ -39,6 +40,8 @@ PROTOTYPES = {
     "vipant_layernorm_fwd": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "vipant_residual_add": (_i32, [_p, _p, _p, _i64, _p]),
     "vipant_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_layernorm_fwd_e4m3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "vipant_layernorm_bwd_e4m3": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p, _p, _p]),
     "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),

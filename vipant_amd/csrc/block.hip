@@ -23,13 +23,32 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 // a . w^T on the bf16 operands, or -- with a plan -- on their e4m3 forms: `a` is row-quantised into the plan's scratch first, the
 // weight comes pre-quantised (wq / ws: the plan's copy of the SAME matrix, same orientation, as the bf16 argument it replaces)
-int32_t nt(const vipant_fp8_plan* plan, const uint8_t* wq, const uint8_t* ws, const uint16_t* a, const uint16_t* w, void* out,
-           const float* bias, void* aux, int64_t M, int64_t N, int64_t K, int32_t epi, void* stream) {
+// (aq, as): the activation already quantised (by the LayerNorm that produced it), or NULL: quantise it here
+int32_t nt(const vipant_fp8_plan* plan, const uint8_t* wq, const uint8_t* ws, const uint8_t* aq, const uint8_t* as,
+           const uint16_t* a, const uint16_t* w, void* out, const float* bias, void* aux, int64_t M, int64_t N, int64_t K,
+           int32_t epi, void* stream) {
     if (plan == nullptr) return vipant_gemm_nt(a, K, w, K, out, N, bias, aux, 1.0f, M, N, K, epi, stream);
     VIPANT_REQUIRE(wq != nullptr && ws != nullptr && plan->act_q != nullptr && plan->act_scale != nullptr, VIPANT_EBADSHAPE,
                    "fp8 plan: quantised weight, its row scales and the activation scratch are all required");
-    TRY(vipant_quant_e4m3_rows(a, K, plan->act_q, K, plan->act_scale, M, K, stream));
-    return vipant_gemm_nt_e4m3(plan->act_q, K, plan->act_scale, wq, K, ws, out, N, bias, aux, M, N, K, epi, stream);
+    if (aq == nullptr) {
+        TRY(vipant_quant_e4m3_rows(a, K, plan->act_q, K, plan->act_scale, M, K, stream));
+        aq = plan->act_q; as = plan->act_scale;
+    }
+    return vipant_gemm_nt_e4m3(aq, K, as, wq, K, ws, out, N, bias, aux, M, N, K, epi, stream);
+}
+
+// LayerNorm backward of a block operator: in place on the stream gradient (fp32 master + bf16 copy, or bf16 only), the new
+// gradient's quantised form written beside it when the plan carries the buffers
+int32_t ln_bwd(const vipant_fp8_plan* plan, const uint16_t* dh, const float* x, const float* mean, const float* rstd,
+               const float* gamma, float* dstream, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
+               int64_t D, void* workspace, size_t workspace_bytes, void* stream) {
+    uint8_t* q = plan ? plan->dy_q : nullptr;
+    uint8_t* qs = plan ? plan->dy_scale : nullptr;
+    if (dstream == nullptr)
+        return vipant_layernorm_bwd_e4m3(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma,
+                                         dbeta, dx_colsum, 0, M, D, workspace, workspace_bytes, q, qs, stream);
+    return vipant_layernorm_bwd_e4m3(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
+                                     D, workspace, workspace_bytes, q, qs, stream);
 }
 
 }  // namespace
@@ -48,9 +67,10 @@ extern "C" int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, f
                                           uint16_t* qkv, int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_qkv_fwd: add and x_out go together");
-    TRY(vipant_layernorm_fwd(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, stream));
-    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, h, w_qkv, qkv, b_qkv, nullptr, M, 3 * D, D,
-              VIPANT_EPI_BF16, stream);
+    TRY(vipant_layernorm_fwd_e4m3(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, plan ? plan->act_q : nullptr,
+                                  plan ? plan->act_scale : nullptr, stream));
+    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
+              plan ? plan->act_scale : nullptr, h, w_qkv, qkv, b_qkv, nullptr, M, 3 * D, D, VIPANT_EPI_BF16, stream);
 }
 
 extern "C" int32_t vipant_ln_qkv_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
@@ -67,16 +87,12 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE, "ln_qkv_bwd: workspace too small");
     // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D])
-    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M, D, 3 * D,
-           VIPANT_EPI_BF16, stream));
+    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M,
+           D, 3 * D, VIPANT_EPI_BF16, stream));
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
     TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
     // ln_1 backward + residual-gradient add, in place on the stream gradient (fp32 master + bf16 copy, or bf16 only)
-    if (dstream == nullptr)
-        return vipant_layernorm_bwd(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma, dbeta,
-                                    dx_colsum, 0, M, D, workspace, workspace_bytes, stream);
-    return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
-                                D, workspace, workspace_bytes, stream);
+    return ln_bwd(plan, dh, x, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, stream);
 }
 
 extern "C" int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x,
@@ -98,8 +114,8 @@ extern "C" int32_t vipant_gemm_bias_residual_fwd_e4m3(const uint16_t* a, const u
                               stream);
     }
     // the step's form: branch output as bf16; the add happens in the next LayerNorm pass
-    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, a, w, out, bias, nullptr, M, N, K, VIPANT_EPI_BF16,
-              stream);
+    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, a, w, out, bias, nullptr, M, N, K,
+              VIPANT_EPI_BF16, stream);
 }
 
 extern "C" int32_t vipant_gemm_bias_residual_fwd(const uint16_t* a, const uint16_t* w, const float* bias,
@@ -114,8 +130,8 @@ extern "C" int32_t vipant_gemm_bias_residual_bwd_e4m3(const uint16_t* dy, const 
     VIPANT_REQUIRE(workspace_bytes >= vipant_gemm_tn_workspace_bytes(M, N, K), VIPANT_ENOWORKSPACE,
                    "gemm_bias_residual_bwd: workspace too small");
     // da[M, K] = dy[M, N] . W[N, K]   (w_t is W^T, [K, N]);  dW[N, K] = dy^T a
-    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, dy, w_t, da, nullptr, nullptr, M, K, N, VIPANT_EPI_BF16,
-           stream));
+    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
+           plan ? plan->dy_scale : nullptr, dy, w_t, da, nullptr, nullptr, M, K, N, VIPANT_EPI_BF16, stream));
     return vipant_gemm_tn(dy, N, a, K, dw, K, M, N, K, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -133,11 +149,12 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const float* x, const uint16
                                                     const vipant_fp8_plan* plan, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: add and x_out go together");
-    TRY(vipant_layernorm_fwd(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, stream));
-    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D,
-           VIPANT_EPI_QUICKGELU_D8, stream));
-    return nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, g, w_proj, y, b_proj, nullptr, M, D, 4 * D,
-              VIPANT_EPI_BF16, stream);
+    TRY(vipant_layernorm_fwd_e4m3(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, plan ? plan->act_q : nullptr,
+                                  plan ? plan->act_scale : nullptr, stream));
+    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
+           plan ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream));
+    return nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, g, w_proj, y, b_proj, nullptr, M,
+              D, 4 * D, VIPANT_EPI_BF16, stream);
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma,
@@ -153,8 +170,8 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* a
 extern "C" int32_t vipant_mlp_quickgelu_recompute_e4m3(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,
                                                        uint16_t* g, int64_t M, int64_t D, const vipant_fp8_plan* plan,
                                                        void* stream) {
-    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D,
-              VIPANT_EPI_QUICKGELU_D8, stream);
+    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D,
+              D, VIPANT_EPI_QUICKGELU_D8, stream);
 }
 
 extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,
@@ -174,19 +191,16 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
                    "ln_mlp_quickgelu_bwd: workspace too small");
     // du = (dy . W_proj) * QuickGELU'(u), the derivative read from its 8-bit code;  dW_proj = dy^T g   (d b_proj is the column
     // sum the caller already has)
-    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M,
-           4 * D, D, VIPANT_EPI_DQUICKGELU_D8, stream));
+    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
+           plan ? plan->dy_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
+           VIPANT_EPI_DQUICKGELU_D8, stream));
     TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
-    TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D, 4 * D,
-           VIPANT_EPI_BF16, stream));
+    TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D,
+           4 * D, VIPANT_EPI_BF16, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
-    if (dstream == nullptr)
-        return vipant_layernorm_bwd(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma, dbeta,
-                                    dx_colsum, 0, M, D, workspace, workspace_bytes, stream);
-    return vipant_layernorm_bwd(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
-                                D, workspace, workspace_bytes, stream);
+    return ln_bwd(plan, dh, x, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, stream);
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t,

@@ -7,13 +7,45 @@ namespace {
 
 constexpr float LN_EPS = 1e-5f;
 
+// Row quantiser of vipant_quant_e4m3_rows (elementwise.hip) on a row that is already in registers, four consecutive elements per
+// lane and 256-column step: the values are first rounded to bf16, so the bytes and the scale are those the stand-alone kernel
+// produces from the bf16 tensor this kernel also writes.
+template <int NV>
+__device__ __forceinline__ void quant_row_e4m3(f32x4 (&o)[NV], uint8_t* __restrict__ qrow, uint8_t* __restrict__ qscale, int lane) {
+    float amax = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const bf16x4 b = f32x4_to_bf16x4(o[t]);
+        o[t] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[t][0]), fabsf(o[t][1])), fmaxf(fabsf(o[t][2]), fabsf(o[t][3]))));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+    int e = 0;
+    if (amax > 0.f) {
+        e = (int)((__float_as_uint(amax) >> 23) & 255u) - 127 - 8;
+        if (amax * __uint_as_float((uint32_t)(127 - e) << 23) > 448.f) e += 1;
+        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+    }
+    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+    if (lane == 0) *qscale = (uint8_t)(e + 127);
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[t][0] * inv, o[t][1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[t][2] * inv, o[t][3] * inv, w, true);
+        *(int*)(qrow + (t * 64 + lane) * 4) = w;
+    }
+}
+
 template <int NV>  // D = NV * 256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t M,
-                                                     const bf16_t* __restrict__ add, float* __restrict__ sum_out) {
+                                                     const bf16_t* __restrict__ add, float* __restrict__ sum_out,
+                                                     uint8_t* __restrict__ q8, uint8_t* __restrict__ q8s) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -52,7 +84,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             const int64_t off = row * D + (t * 64 + lane) * 4;
             if (y != nullptr) *(bf16x4*)(y + off) = f32x4_to_bf16x4(o);
             if (y32 != nullptr) *(f32x4*)(y32 + off) = o;
+            v[t] = o;
         }
+        if (q8 != nullptr) quant_row_e4m3<NV>(v, q8 + row * D, q8s + row, lane);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -66,7 +100,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const void* dres_, float* dx, int64_t lddx,
-                                                     bf16_t* dxb, float* __restrict__ partial, int64_t M) {
+                                                     bf16_t* dxb, float* __restrict__ partial, int64_t M,
+                                                     uint8_t* __restrict__ q8, uint8_t* __restrict__ q8s) {
     const float* dres = DRES_BF16 ? nullptr : (const float*)dres_;
     const bf16_t* dresb = DRES_BF16 ? (const bf16_t*)dres_ : nullptr;
     constexpr int D = NV * 256;
@@ -117,7 +152,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             dsum[t] += o;
             if (dx != nullptr) *(f32x4*)(dx + row * lddx + col) = o;
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
+            g[t] = o;
         }
+        if (q8 != nullptr) quant_row_e4m3<NV>(g, q8 + row * D, q8s + row, lane);
     }
     // block reduction of the 4 waves' column sums, one quantity at a time through a [4][D] LDS buffer (12 KiB at
     // D = 768: does not limit residency), then one row of partials per BLOCK
@@ -165,9 +202,10 @@ int ln_blocks(int64_t M) {
 
 }  // namespace
 
-extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
-                                        uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
-                                        const uint16_t* add, float* sum_out, void* stream) {
+extern "C" int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                             uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
+                                             const uint16_t* add, float* sum_out, uint8_t* q, uint8_t* qscale, void* stream) {
+    VIPANT_REQUIRE((q == nullptr) == (qscale == nullptr), VIPANT_EBADSHAPE, "layernorm_fwd: q and qscale go together");
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
                    "layernorm_fwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
     VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
@@ -176,7 +214,7 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
     const int blocks = (int)(ceil_div(M, 4) > (1 << 20) ? (1 << 20) : ceil_div(M, 4));
 #define LN_FWD(NV)                                                                                                   \
     hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, y_f32, mean, \
-                       rstd, M, (const bf16_t*)add, sum_out)
+                       rstd, M, (const bf16_t*)add, sum_out, q, qscale)
     switch (D / 256) {
         case 1: LN_FWD(1); break;
         case 2: LN_FWD(2); break;
@@ -188,15 +226,22 @@ extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float
     return VIPANT_OK;
 }
 
+extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                        uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
+                                        const uint16_t* add, float* sum_out, void* stream) {
+    return vipant_layernorm_fwd_e4m3(x, ldx, gamma, beta, y, y_f32, mean, rstd, M, D, add, sum_out, nullptr, nullptr, stream);
+}
+
 extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
     return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
-extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx,
-                                        const float* mean, const float* rstd, const float* gamma, const void* dres,
-                                        float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
-                                        float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const float* x, int64_t ldx,
+                                             const float* mean, const float* rstd, const float* gamma, const void* dres,
+                                             float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
+                                             float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
+                                             size_t workspace_bytes, uint8_t* q, uint8_t* qscale, void* stream) {
+    VIPANT_REQUIRE((q == nullptr) == (qscale == nullptr), VIPANT_EBADSHAPE, "layernorm_bwd: q and qscale go together");
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
                    "layernorm_bwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
     VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && lddx >= D && lddx % 4 == 0, VIPANT_EALIGN, "layernorm_bwd: bad strides");
@@ -212,13 +257,13 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const flo
     do {                                                                                                             \
         if (dy_is_f32)                                                                                               \
             hipLaunchKernelGGL((ln_bwd_kernel<NV, true, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
         else if (dres_bf16)                                                                                          \
             hipLaunchKernelGGL((ln_bwd_kernel<NV, false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
         else                                                                                                         \
             hipLaunchKernelGGL((ln_bwd_kernel<NV, false, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M);                              \
+                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
     } while (0)
     switch (D / 256) {
         case 1: LN_BWD(1); break;
@@ -232,4 +277,13 @@ extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const flo
                        (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx,
+                                        const float* mean, const float* rstd, const float* gamma, const void* dres,
+                                        float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
+                                        float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    return vipant_layernorm_bwd_e4m3(dy, flags, x, ldx, mean, rstd, gamma, dres, dx_f32, lddx, dx_bf16, dgamma, dbeta, dx_colsum,
+                                     accumulate, M, D, workspace, workspace_bytes, nullptr, nullptr, stream);
 }

@@ -279,12 +279,13 @@ def cast_weights(weights: Sequence[torch.Tensor], e4m3: bool = False):
     return wb, wt
 
 
-def fp8_plan(w=None, w2=None, act=None):
+def fp8_plan(w=None, w2=None, act=None, dyq=None):
     """struct vipant_fp8_plan for one fused-operator call: w / w2 = (bytes, row scales) of the operator's weights, act = (scratch
-    bytes [M, 4D], scratch row scales [M])."""
+    bytes [M, 4D], scratch row scales [M]), dyq = (bytes [M, D], row scales [M]): the quantised stream gradient that travels
+    between the backward operators."""
     from ._ffi import Fp8Plan
     return Fp8Plan(w[0].data_ptr(), w[1].data_ptr(), w2[0].data_ptr() if w2 else None, w2[1].data_ptr() if w2 else None,
-                   act[0].data_ptr(), act[1].data_ptr())
+                   act[0].data_ptr(), act[1].data_ptr(), dyq[0].data_ptr() if dyq else None, dyq[1].data_ptr() if dyq else None)
 
 
 _frozen_cache: Dict[tuple, tuple] = {}
@@ -493,7 +494,10 @@ class BackboneFn(torch.autograd.Function):
             dx = None
             dx_b = cast_bf16_flat(dx_in.contiguous())
         ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
-        act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev)) if fp8 else None
+        act = dyq = None
+        if fp8:
+            act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev))
+            dyq = quant_e4m3(dx_b)      # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
         du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
         dh = torch.empty((M, D), dtype=BF16, device=dev)
         do = torch.empty((M, D), dtype=BF16, device=dev)
@@ -520,17 +524,17 @@ class BackboneFn(torch.autograd.Function):
                  h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[3], wtq4[2], act)) if fp8 else None, st)
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq)) if fp8 else None, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
-                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act)) if fp8 else None, st)
+                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq)) if fp8 else None, st)
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
             call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[0], None, act)) if fp8 else None, st)
+                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None, st)
             del dqkv
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
