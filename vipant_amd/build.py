@@ -7,7 +7,9 @@ newer than the object) and the objects are linked into the library.
 from __future__ import annotations
 
 import glob
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -22,6 +24,35 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # machine sinker moves all 32 of a K-tile below both barriers (into the loop latch), which undoes the ping-pong schedule and
 # spills 25 registers: 1.18 -> 1.69 PFLOP/s at K = 1024 with the pass off; the bf16 kernels of the file compile to the same code.
 EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink"]}
+
+
+_REMARK_ECHO = re.compile(r"^\s*(\d+ \||\|)")      # the source-line echo clang prints under each remark
+
+
+def _resource_usage(stderr: str):
+    """{kernel: {field: int}} from clang's -Rpass-analysis=kernel-resource-usage remarks (registers, spills, scratch, LDS)."""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z \[\]/]+):\s*(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2)
+        if key == "Function Name":
+            cur = out.setdefault(val, {})
+        elif cur is not None and val.lstrip("-").isdigit():
+            cur[key] = int(val)
+    return out
+
+
+def resource_usage():
+    """Per-kernel resource usage of the last build: {source file: {kernel: {field: int}}}."""
+    res = {}
+    for s in sources():
+        p = _obj(s)[:-2] + ".resources.json"
+        if os.path.exists(p):
+            with open(p) as f:
+                res[os.path.basename(s)] = json.load(f)
+    return res
 
 
 def sources():
@@ -52,13 +83,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _headers()
-    todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs)]
+    todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs) or not os.path.exists(_obj(s)[:-2] + ".resources.json")]
 
     def compile_one(src):
-        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(os.path.basename(src), []), "-c", src, "-o", _obj(src)]
+        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(os.path.basename(src), []), "-Rpass-analysis=kernel-resource-usage", "-c", src,
+               "-o", _obj(src)]
         if verbose:
             print("[vipant_amd.build]", " ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        usage = _resource_usage(r.stderr)
+        other = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not _REMARK_ECHO.match(l))
+        if other.strip():
+            sys.stderr.write(other + "\n")
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(_obj(src)[:-2] + ".resources.json", "w") as f:
+            json.dump(usage, f, indent=0)
+        for name, u in usage.items():
+            if u.get("VGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0):
+                print(f"[vipant_amd.build] WARNING {os.path.basename(src)}: {name} spills "
+                      f"({u.get('VGPRs Spill', 0)} VGPRs, {u.get('ScratchSize [bytes/lane]', 0)} B/lane of scratch)", flush=True)
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as pool:
         list(pool.map(compile_one, todo))
