@@ -177,3 +177,29 @@ def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
     ops.call("vipant_layernorm_bwd", dy.data_ptr(), 2, xs.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
              dxb2.data_ptr(), None, D, dxb2.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(), st)
     assert torch.equal(dxb, dxb2)
+
+
+def test_e4m3_stack_with_recomputed_mlp_is_bit_identical(ops):
+    """`running.recompute_mlp` under `running.fp8_gemm`: the backward re-runs the e4m3 c_fc contraction from the saved LayerNorm
+    output; same bytes in, same bytes out -- activations and every gradient equal the plain e4m3 run bit for bit."""
+    from types import SimpleNamespace as NS
+    import gen
+    import vipant_amd.module as Mod
+    D, layers, b, S = 768, 2, 4, 50
+    bb = Mod.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=D, ctx_len=None)
+    w = gen.det_weights("full/768", gen.backbone_shapes(D, layers))
+    bb.load_state_dict({k[len("encoder."):]: v for k, v in w.items()}, strict=True)
+    bb = bb.to(DEV)
+    bb.fp8 = True
+    x, gy = rnd(b, S, D, seed=41), rnd(b, S, D, seed=42)
+    outs = []
+    for rc in (False, True):
+        bb.recompute_mlp = rc
+        for p in bb.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_()
+        y = bb(xi)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in bb.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, c) for a, c in zip(outs[0][2], outs[1][2]))

@@ -226,3 +226,12 @@ def test_checkpoint_round_trip_into_at_build_and_eval(tmp_path):
     bad.rank = 0
     with pytest.raises(Exception):
         build_main_model(bad, lambda *_: None).build()
+
+
+def test_fp8_switch_is_off_by_default_and_composes():
+    """`running.fp8_gemm` (BASELINE.json configs[4]) defaults to False -- the headline configuration is bf16 -- and parses as a bool."""
+    from vipant_amd.config import compose
+    base = ("+running=bimodal worker=CVALP mode=dp eval=False +model/image=vit_val +model/audio=vit_val +model/text=dummy "
+            "+model/loss=ce +optimizer=standard +running/audio=default").split()
+    assert compose(base).running.get("fp8_gemm", None) is False
+    assert compose(base + ["running.fp8_gemm=True"]).running.fp8_gemm is True
