@@ -499,6 +499,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
 // instruction immediate, so the call sites are spelled out with literal selectors (a `switch` on the unrolled loop index
 // compiled, but left the MFMAs in blocks of their own, and the machine sinker then moved all 32 of a K-tile below both barriers).
 template <int V> struct Int { static constexpr int value = V; };
+#define VIPANT_BF(ACC, B4, A4) \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, i32x4(B4)), __builtin_bit_cast(bf16x8, i32x4(A4)), ACC, 0, 0, 0)
 #define VIPANT_MX(ACC, A, B, OA, SA, OB, SB) \
     ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, ACC, 0, 0, OA, (int)(SA), OB, (int)(SB))
 
@@ -669,10 +671,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             ga[(II + 1) & 1].lo = *(const i32x4*)(sa0 + (II + 1) * 2048);                  \
             ga[(II + 1) & 1].hi = *(const i32x4*)(sa1 + (II + 1) * 2048);                  \
         }                                                                                  \
-        VIPANT_MX(acc[h * 4 + II][0], gb[0], ga[II & 1], 0, sbv, II, sah);                 \
-        VIPANT_MX(acc[h * 4 + II][1], gb[1], ga[II & 1], 1, sbv, II, sah);                 \
-        VIPANT_MX(acc[h * 4 + II][2], gb[2], ga[II & 1], 2, sbv, II, sah);                 \
-        VIPANT_MX(acc[h * 4 + II][3], gb[3], ga[II & 1], 3, sbv, II, sah);                 \
+        if (ES == 1) {                                                                     \
+            VIPANT_MX(acc[h * 4 + II][0], gb[0], ga[II & 1], 0, sbv, II, sah);             \
+            VIPANT_MX(acc[h * 4 + II][1], gb[1], ga[II & 1], 1, sbv, II, sah);             \
+            VIPANT_MX(acc[h * 4 + II][2], gb[2], ga[II & 1], 2, sbv, II, sah);             \
+            VIPANT_MX(acc[h * 4 + II][3], gb[3], ga[II & 1], 3, sbv, II, sah);             \
+        } else {        /* bf16 under the DEEP schedule: k-step 0 of the four column tiles, then k-step 1 */ \
+            VIPANT_BF(acc[h * 4 + II][0], gb[0].lo, ga[II & 1].lo); VIPANT_BF(acc[h * 4 + II][1], gb[1].lo, ga[II & 1].lo); \
+            VIPANT_BF(acc[h * 4 + II][2], gb[2].lo, ga[II & 1].lo); VIPANT_BF(acc[h * 4 + II][3], gb[3].lo, ga[II & 1].lo); \
+            VIPANT_BF(acc[h * 4 + II][0], gb[0].hi, ga[II & 1].hi); VIPANT_BF(acc[h * 4 + II][1], gb[1].hi, ga[II & 1].hi); \
+            VIPANT_BF(acc[h * 4 + II][2], gb[2].hi, ga[II & 1].hi); VIPANT_BF(acc[h * 4 + II][3], gb[3].hi, ga[II & 1].hi); \
+        }                                                                                  \
         __builtin_amdgcn_sched_barrier(0);
         VIPANT_MX_ROW(0) VIPANT_MX_ROW(1) VIPANT_MX_ROW(2) VIPANT_MX_ROW(3)
 #undef VIPANT_MX_ROW
@@ -851,11 +860,17 @@ int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     if ((p.dbg & 768) == 512) return launch_pp_variant<EPI, 5>(p, stream);
     if ((p.dbg & 768) == 768) return launch_pp_variant<EPI, 6>(p, stream);
     if (p.dbg & 8192) return launch_pp_variant<EPI, 9>(p, stream);
+    if (p.dbg & 131072) return launch_pp_variant<EPI, 10>(p, stream);      // DEEP schedule on bf16 operands
     const bool groupable = ceil_div(p.N, BN) % 2 == 0 && ceil_div(p.M, BM) * ceil_div(p.N, BN) >= 256;
     if ((p.dbg & 1024) && groupable) return launch_pp_variant<EPI, 7>(p, stream);
     // the column-grouped walk is the default of the c_fc launch (853 vs 870-881 us, step -0.27 ms in-box; the QuickGELU' launch of
     // the same shape does not move: profiles/r2_gemm_experiments.md section 9); bit 11 forces it everywhere, bit 12 turns it off
     if (groupable && !(p.dbg & 4096) && (EPI == VIPANT_EPI_QUICKGELU_D8 || (p.dbg & 2048))) return launch_pp_variant<EPI, 8>(p, stream);
+    // the DEEP schedule (three barrier intervals of look-ahead for every operand piece, intervals by row halves): -2 ... -5 % on the
+    // launches with a long K or a wide N (qkv 608-624 -> 589-603 us, QuickGELU' 933-947 -> 916, dh2 627-634 -> 596-604), +3 % on the
+    // 768 x 768 ones, which keep the k-step schedule; bit 18 of VIPANT_GEMM_VARIANT: off
+    if (!(p.dbg & 262144) && (EPI == VIPANT_EPI_DQUICKGELU_D8 || (EPI == VIPANT_EPI_BF16 && (p.N >= 1024 || p.K >= 1024))))
+        return launch_pp_variant<EPI, 10>(p, stream);
     return launch_pp_variant<EPI, 0>(p, stream);
 }
 
