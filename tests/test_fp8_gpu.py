@@ -132,7 +132,10 @@ def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
         return float((a.double() - ref.double()).norm() / ref.double().norm())
     assert not torch.equal(y0, y1)                                   # the e4m3 path really ran
     worst = max((rel(g1[k], g0[k]), k) for k in g0)
-    with open("gpurun_out/fp8_block_observed.txt", "w") as f:
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fp8_block_observed.txt"), "w") as f:
         f.write("rel-L2 e4m3 vs bf16 block stack (2 blocks, b=8, S=316): y %.3e, dx %.3e, worst parameter gradient %.3e (%s)\n"
                 % (rel(y1, y0), rel(dx1, dx0), worst[0], worst[1]))
     # per contraction the e4m3 operands cost ~4e-2 relative (two factors of 2^-4 / sqrt(3) each, tests above); the deterministic
