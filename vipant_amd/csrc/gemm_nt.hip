@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // experiment (VAR 7 / 8): column-grouped walk -- the XCDs split into two column groups (each keeps HALF of the weight matrix,
     // meant to stay in its 4 MiB L2) times four row quarters; a workgroup's sequence number then maps to (panel, column) inside
     // its XCD's share.  Needs the full grid of 256 and an even number of column tiles.
-    constexpr bool GROUPED = VAR == 7 || VAR == 8;
+    constexpr bool GROUPED = VAR == 8;
     const int G = gridDim.x;                                   // multiple of 8, <= ntiles rounded up
     const int cg = ntn / 2, ppx = (ntm + 3) / 4;
     const int ntiles = GROUPED ? ((ppx * cg + 31) / 32) * 256 : ntm * ntn;
@@ -608,8 +608,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         fa[0] = *(const bf16x8*)(sa);
         fa[1] = *(const bf16x8*)(sa + 2048);
     };
-    // 32 MFMAs of k-step ks; `dma(i)` is called after MFMA group i (used to spread the K-tile's DMA issue over the groups)
-    auto half_body = [&](int ks, int stage, auto&& dma) {
+    // 32 MFMAs of k-step ks
+    auto half_body = [&](int ks, int stage) {
         const char* sa = smem + stage * PP_A_STAGE + offA[ks];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -618,7 +618,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i % 3], acc[i][j], 0, 0, 0);
-            dma(i);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -765,57 +764,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 const uint32_t kb = grp == 0 ? ka : (uint32_t)((w2 ? k + 2 - nk : k + 2) * BK * 2);
                 char* const da = ldsA + (stage ^ 1) * PP_A_STAGE;
                 char* const db = ldsB + (grp == 0 ? slot1 : slot2) * PP_B_SLOT;
-                auto dma_piece = [&](int i) {      // piece i of this wave's 8: 4 of A, then 4 of B
-                    if (i < 4) {
-                        if (VAR == 4 || VAR == 6 || VAR == 7)       // experiment: non-temporal hint on the streamed operand
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (LDS_AS void*)(da + i * 1024), 16, voffA[i & 1],
-                                                                     ka + waveA + (i >> 1) * pairA, 0, 2);
-                        else lds_dma16(ra, da + i * 1024, voffA[i & 1], ka + waveA + (i >> 1) * pairA);
-                    } else {
-                        if (VAR == 5 || VAR == 6)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (LDS_AS void*)(db + (i - 4) * 1024), 16, voffB[i & 1],
-                                                                     kb + waveB + ((i - 4) >> 1) * pairB, 0, 2);
-                        else lds_dma16(rb, db + (i - 4) * 1024, voffB[i & 1], kb + waveB + ((i - 4) >> 1) * pairB);
-                    }
-                };
-                if (VAR == 1) {                    // fragment reads first: their LDS round trip runs under the DMA issue
-                    frag_head(0, stage, slot);
-                    __builtin_amdgcn_sched_barrier(0);
+                // the K-tile's eight pieces as one burst at its top: 4 of A, then 4 of B.  (Measured and not kept, see
+                // profiles/r2_gemm_experiments.md: fragment reads before the burst, the pieces spread behind the MFMA groups, raised
+                // MFMA priority, `nt` hints on either operand, the burst half a K-tile later.)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dma_piece(i);
-                } else if (VAR == 3) {             // spread: one piece behind each MFMA group of k-step 0
-                    frag_head(0, stage, slot);
-                } else {                           // burst at the top of the K-tile (VAR 9, look-ahead probe: at its middle)
-                    if (VAR != 9) {
+                for (int i = 0; i < 4; ++i) lds_dma16(ra, da + i * 1024, voffA[i & 1], ka + waveA + (i >> 1) * pairA);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) dma_piece(i);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (ES == 1) frag_head8(Int<0>{}, stage, slot); else
-                    frag_head(0, stage, slot);
-                }
-                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                for (int i = 0; i < 4; ++i) lds_dma16(rb, db + i * 1024, voffB[i & 1], kb + waveB + (i >> 1) * pairB);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ES == 1) frag_head8(Int<0>{}, stage, slot); else
+                frag_head(0, stage, slot);
                 if (ES == 1) half_body8(Int<0>{}, stage); else
-                if (VAR == 3) half_body(0, stage, dma_piece); else
-                half_body(0, stage, [](int) {});
-                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
-                if (grp == 1) {
-                    if (VAR == 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                }
+                half_body(0, stage);
+                if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 sync();
                 // second interval: k-step 1
-                if (VAR == 9) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dma_piece(i);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (ES == 1) frag_head8(Int<1>{}, stage, slot); else
                 frag_head(1, stage, slot);
-                if (VAR == 2) __builtin_amdgcn_s_setprio(1);
                 if (ES == 1) half_body8(Int<1>{}, stage); else
-                half_body(1, stage, [](int) {});
-                if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+                half_body(1, stage);
                 if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sync();
@@ -853,16 +820,9 @@ int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
 
 template <int EPI>
 int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
-    if (p.dbg & 32) return launch_pp_variant<EPI, 1>(p, stream);
-    if (p.dbg & 64) return launch_pp_variant<EPI, 2>(p, stream);
-    if (p.dbg & 128) return launch_pp_variant<EPI, 3>(p, stream);
-    if ((p.dbg & 768) == 256) return launch_pp_variant<EPI, 4>(p, stream);
-    if ((p.dbg & 768) == 512) return launch_pp_variant<EPI, 5>(p, stream);
-    if ((p.dbg & 768) == 768) return launch_pp_variant<EPI, 6>(p, stream);
-    if (p.dbg & 8192) return launch_pp_variant<EPI, 9>(p, stream);
-    if (p.dbg & 131072) return launch_pp_variant<EPI, 10>(p, stream);      // DEEP schedule on bf16 operands
+    // schedules of the ping-pong kernel: 0 = k-step intervals, 8 = the same on the column-grouped tile walk, 10 = DEEP
+    if (p.dbg & 131072) return launch_pp_variant<EPI, 10>(p, stream);      // bit 17: DEEP for every launch (A/B)
     const bool groupable = ceil_div(p.N, BN) % 2 == 0 && ceil_div(p.M, BM) * ceil_div(p.N, BN) >= 256;
-    if ((p.dbg & 1024) && groupable) return launch_pp_variant<EPI, 7>(p, stream);
     // the column-grouped walk is the default of the c_fc launch (853 vs 870-881 us, step -0.27 ms in-box; the QuickGELU' launch of
     // the same shape does not move: profiles/r2_gemm_experiments.md section 9); bit 11 forces it everywhere, bit 12 turns it off
     if (groupable && !(p.dbg & 4096) && (EPI == VIPANT_EPI_QUICKGELU_D8 || (p.dbg & 2048))) return launch_pp_variant<EPI, 8>(p, stream);
