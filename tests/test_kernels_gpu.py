@@ -133,7 +133,8 @@ def qgelu_prime(u):
     return sg * (1 + 1.702 * u * (1 - sg))
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 3072, 768), (300, 264, 128), (70000, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(1000, 3072, 768), (300, 264, 128), (70000, 1024, 256),
+                                   (33100, 3072, 128)])     # 130 x 12 tiles: the column-grouped walk with ragged row quarters
 def test_gemm_nt_quickgelu_derivative_code(ops, M, N, K):
     """The two-output epilogues with the 8-bit QuickGELU' code (what the step uses): g as before; the code decodes to
     QuickGELU'(pre-activation) within half a code step (2.4e-3) plus the bf16 rounding of the pre-activation; the backward
