@@ -356,9 +356,23 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // The tile epilogue of the ping-pong kernels: 4 rounds of 32 rows of the group's 128 x 256 accumulator block staged through 16 KiB
 // of LDS (`stg`, free for this group at this point of its stream) and written out row-contiguous, with the epilogue arithmetic.
+// the 8-bit QuickGELU' codes one thread needs for epilogue round r of its group's block (four 8-byte loads)
+__device__ __forceinline__ void load_codes(const GemmNT& p, int m0, int n0, int grp, int tl, int r, u32x2 (&cn)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int idx = t * 256 + tl;
+        const int R = idx >> 5, ch = idx & 31;
+        const int m = m0 + grp * 128 + (r * 2 + (R >> 4)) * 16 + (R & 15), n = n0 + ch * 8;
+        cn[t] = (m < p.M && n < p.N) ? *(const u32x2*)((const uint8_t*)p.aux + (int64_t)m * p.ldc + n) : u32x2{0u, 0u};
+    }
+}
+
+// `pre`: the codes of round 0, requested by the caller during the tile's last K-tile (QuickGELU' launch on the DEEP schedule: the
+// HBM round trip of the first round's codes is then off the epilogue's critical path), or NULL
 template <int EPI>
 __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], const f32x4 (&bv)[4], char* stg, char* stg_hi,
-                                            int m0, int n0, int grp, int wl, int frow, int fq, int tid) {
+                                            int m0, int n0, int grp, int wl, int frow, int fq, int tid,
+                                            const u32x2 (*pre)[4] = nullptr) {
     // rows 0-15 of a round are staged at `stg`, rows 16-31 at `stg_hi` (the ring kernel has two free 8-KiB pieces, not one of 16)
     stg_hi -= 16 * 512;
     auto sync = [&]() {
@@ -383,7 +397,14 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
             else un[t] = ok ? *(const bf16x8*)((const bf16_t*)p.aux + (int64_t)m * p.ldc + n) : bf16x8{};
         }
     };
-    if (GELU_IN) load_aux(0);
+    if (GELU_IN) {
+        if (pre != nullptr) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cn[t] = (*pre)[t];
+        } else {
+            load_aux(0);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -724,11 +745,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 bv[4];
+        constexpr bool PRE_CODES = DEEP && EPI == VIPANT_EPI_DQUICKGELU_D8;
+        u32x2 cn_pre[4];
         for (int k = 0; k < nk; ++k) {
             const int stage = gk & 1;
             const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
+                if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);    // not awaited here
                 if (ES == 1) load_scales(nxt, sav_n, sbv_n);                  // the next tile's scales ride the same round trip
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
@@ -793,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
-        pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid);
+        pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile += G;
         cur = nxt;
         nxt = describe(tile + G);
