@@ -15,6 +15,14 @@ Nyquist, log with an epsilon floor), anchored on the reference's own call sites:
   * configs/running/audio/default.yaml   FrequencyMasking(32), TimeMasking(200), zero_mean_wf: True
 
 No golden vector from torchaudio itself could be generated here, so tests pin the HIP kernels to THIS file only.
+
+Cross-check (round 2; it does not lift the "unpinned" status above): an independent Kaldi-compatible implementation that IS
+importable in the build container -- `transformers.audio_utils.spectrogram` (transformers 5.15.0), the numpy fallback HuggingFace's
+ASTFeatureExtractor uses in place of `torchaudio.compliance.kaldi.fbank` when torchaudio is missing -- run with the reference's
+parameters agrees with `kaldi_fbank` below on four waveforms at 16 / 22.05 / 44.1 kHz, 64 and 128 bins: median difference 5e-6,
+maximum 3e-3 (on bins at ~1e-6 of their frame's loudest energy: float32 FFT round-off here, float64 there), log energies in
+[-15.9, 7].  Vectors: tests/golden/fbank_crosscheck.npz (made by tests/golden/make_fbank_crosscheck.py); test:
+tests/test_fbank_oracle_cpu.py::test_oracle_agrees_with_an_independent_kaldi_compatible_implementation.
 """
 from __future__ import annotations
 
