@@ -78,6 +78,22 @@ def test_two_replicas_match_single_process(tmp_path):
         assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
 
 
+@pytest.mark.timeout(900)
+def test_four_replicas_match_single_process(tmp_path):
+    """The same invariant at world 4 (per-rank batch 4: row offsets 0 / 4 / 8 / 12 of the global similarity matrix -- strips that do
+    not start on a multiple of 8 -- four gradient buckets per block in flight): four replicas sharing the GPU over gloo take the step
+    of one process fed the concatenated batch."""
+    one, four = str(tmp_path / "one.pt"), str(tmp_path / "four.pt")
+    mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(4, _free_port(), four), nprocs=4, join=True)
+    a, b = torch.load(one), torch.load(four)
+    assert abs(a["loss"] - b["loss"]) < 1e-5, (a["loss"], b["loss"])
+    for k in a["params"]:
+        pa, pb = a["params"][k], b["params"][k]
+        err = float((pa - pb).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
 @pytest.mark.timeout(600)
 def test_rccl_call_path_single_rank_is_identity(tmp_path):
     """The RCCL code path itself (flat feature all-gather, per-block bucket all-reduce on the side stream, copy-back into
