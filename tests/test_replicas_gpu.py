@@ -79,6 +79,20 @@ def test_two_replicas_match_single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_eight_replicas_match_single_process(tmp_path):
+    """World 8, the replica count of BASELINE.json configs[3] / configs[4] (per-rank batch 2 here): same invariant."""
+    one, eight = str(tmp_path / "one.pt"), str(tmp_path / "eight.pt")
+    mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(8, _free_port(), eight), nprocs=8, join=True)
+    a, b = torch.load(one), torch.load(eight)
+    assert abs(a["loss"] - b["loss"]) < 1e-5, (a["loss"], b["loss"])
+    for k in a["params"]:
+        pa, pb = a["params"][k], b["params"][k]
+        err = float((pa - pb).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
+@pytest.mark.timeout(900)
 def test_four_replicas_match_single_process(tmp_path):
     """The same invariant at world 4 (per-rank batch 4: row offsets 0 / 4 / 8 / 12 of the global similarity matrix -- strips that do
     not start on a multiple of 8 -- four gradient buckets per block in flight): four replicas sharing the GPU over gloo take the step
