@@ -413,6 +413,23 @@ def test_activation_memory_plans_keep_the_step():
         assert err <= 1e-6 + 1e-4 * float(p0[k].abs().max()), (k, err)
 
 
+def test_e4m3_step_under_the_activation_memory_plans():
+    """`running.fp8_gemm` through the trainer (VAMonitor.step): the loss stays within the e4m3 noise of the bf16 step, recompute is
+    bit-identical, micro-batching equal up to fp32 summation order -- the three switches of the configs[4] bench leg together."""
+    l0, _ = _va_step([])
+    l1, p1 = _va_step(["running.fp8_gemm=True"])
+    assert abs(l1 - l0) < 2e-2 * abs(l0), (l0, l1)
+    l2, p2 = _va_step(["running.fp8_gemm=True", "running.recompute_mlp=True"])
+    assert l1 == l2
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
+    l3, p3 = _va_step(["running.fp8_gemm=True", "running.micro_batch=8", "running.recompute_mlp=True"])
+    assert abs(l1 - l3) < 1e-6, (l1, l3)
+    for k in p1:
+        err = float((p1[k] - p3[k]).abs().max())
+        assert err <= 1e-6 + 1e-4 * float(p1[k].abs().max()), (k, err)
+
+
 @pytest.mark.parametrize("tag", ["va", "at"])
 def test_trainer_trajectory_golden(M, golden, tag):
     """Four optimisation steps of the product path -- heads, loss head, fused LARS, `adjust_learning_rate` -- against the

@@ -415,8 +415,10 @@ class BackboneFn(torch.autograd.Function):
         if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
-        fp8 = bool(fp8) and train       # e4m3 operands in the NT contractions of a trainable tower (configs[4]); frozen towers: bf16
-        if train:               # bf16 copies (W and W^T) of the 4 L weight matrices: one launch per step
+        # e4m3 operands in the NT contractions (configs[4]): a property of the tower, whether or not this call records a backward --
+        # the no-grad feature pass of `running.micro_batch` and evaluation must see the forward the training pass differentiates
+        fp8 = bool(fp8)
+        if train or fp8:        # bf16 copies (W and W^T) of the 4 L weight matrices: one launch per step
             mats = [params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)]
             if fp8:
                 wb_all, wt_all, wq_all, wtq_all = cast_weights(mats, e4m3=True)
@@ -425,19 +427,19 @@ class BackboneFn(torch.autograd.Function):
                 wb_all, wt_all = cast_weights(mats)
         for l in range(L):
             ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, wfc, bfc, wpr, bpr = (p.detach() for p in params[12 * l:12 * l + 12])
+            if fp8:
+                q_qkv, q_o, q_fc, q_pr = wq_all[4 * l:4 * l + 4]
             if train:
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4]
                 wqkv_t, wo_t, wfc_t, wpr_t = wt_all[4 * l:4 * l + 4]
                 wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None) +
                            ((wq_all[4 * l:4 * l + 4], wtq_all[4 * l:4 * l + 4]) if fp8 else (None, None)))
-                if fp8:
-                    q_qkv, q_o, q_fc, q_pr = wq_all[4 * l:4 * l + 4]
                 h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
                 mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
                 if keep_mlp:
                     u, g = new(4 * D, torch.uint8), new(4 * D)
             else:
-                wqkv_b, wo_b, wfc_b, wpr_b = (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
+                wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
             # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
             xs = new(D, F32) if y_prev is not None else None
