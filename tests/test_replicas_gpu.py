@@ -32,7 +32,7 @@ def _batch(B):
     return torch.randn(B, 512, generator=g), torch.randn(B, 1, 256, 64, generator=g)
 
 
-def _run(rank, world, port, out, backend="gloo"):
+def _run(rank, world, port, out, backend="gloo", extra=()):
     if world > 1 or backend == "nccl":
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         if backend == "nccl":                       # single-rank RCCL group with the exchange steps forced on
@@ -47,7 +47,7 @@ def _run(rank, world, port, out, backend="gloo"):
         from vipant_amd.monitor import VAMonitor
         B = 16
         b = B // world
-        cfg = compose(OV + [f"running.batch_size={b}"])
+        cfg = compose(OV + [f"running.batch_size={b}"] + list(extra))
         cfg.rank = 0
         torch.manual_seed(cfg.seed)
         mon = VAMonitor(cfg, lambda *_: None, torch.device("cuda:0"))
@@ -72,6 +72,21 @@ def test_two_replicas_match_single_process(tmp_path):
     a, b = torch.load(one), torch.load(two)
     assert abs(a["loss"] - b["loss"]) < 1e-5, (a["loss"], b["loss"])
     assert a["params"].keys() == b["params"].keys()
+    for k in a["params"]:
+        pa, pb = a["params"][k], b["params"][k]
+        err = float((pa - pb).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
+@pytest.mark.timeout(900)
+def test_two_replicas_match_single_process_with_e4m3_contractions(tmp_path):
+    """`running.fp8_gemm` under replicas: the row quantisation is per sample, so the invariant is untouched."""
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    fp8 = ("running.fp8_gemm=True",)
+    mp.spawn(_run, args=(1, 0, one, "gloo", fp8), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), two, "gloo", fp8), nprocs=2, join=True)
+    a, b = torch.load(one), torch.load(two)
+    assert abs(a["loss"] - b["loss"]) < 1e-5, (a["loss"], b["loss"])
     for k in a["params"]:
         pa, pb = a["params"][k], b["params"][k]
         err = float((pa - pb).abs().max())
