@@ -94,6 +94,21 @@ def test_two_replicas_match_single_process_with_e4m3_contractions(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_two_replicas_with_micro_batches_match_single_process(tmp_path):
+    """`running.micro_batch` under replicas (every micro-batch's backward hands its own gradient buckets to the reduction; a
+    parameter's reduced slices are summed): two replicas running two micro-batches each equal one process on the whole batch."""
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), two, "gloo", ("running.micro_batch=4",)), nprocs=2, join=True)
+    a, b = torch.load(one), torch.load(two)
+    assert abs(a["loss"] - b["loss"]) < 1e-5, (a["loss"], b["loss"])
+    for k in a["params"]:
+        pa, pb = a["params"][k], b["params"][k]
+        err = float((pa - pb).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
+@pytest.mark.timeout(900)
 def test_eight_replicas_match_single_process(tmp_path):
     """World 8, the replica count of BASELINE.json configs[3] / configs[4] (per-rank batch 2 here): same invariant."""
     one, eight = str(tmp_path / "one.pt"), str(tmp_path / "eight.pt")
