@@ -413,6 +413,43 @@ def test_activation_memory_plans_keep_the_step():
         assert err <= 1e-6 + 1e-4 * float(p0[k].abs().max()), (k, err)
 
 
+def test_no_grad_forward_sees_the_optimizer_update():
+    """The fused LARS kernel writes the parameters through raw pointers; torch must still learn that they changed, or the bf16
+    weight cache of no-grad forwards keeps serving the first weights it saw.  (Found in round 2: evaluation after training steps
+    and the feature pass of `running.micro_batch` read stale weights from the second step on.)  After one optimiser step the loss
+    of the updated model is the same through the no-grad path and through the recording path, and a micro-batched run follows the
+    one-pass trajectory over three steps."""
+    from vipant_amd.config import compose
+    from vipant_amd.module import adjust_learning_rate
+    from vipant_amd.monitor import VAMonitor
+    base = ("+running=bimodal worker=CVALP mode=dp eval=False num_gpus=1 +model/image=vit_val +model/audio=vit_val "
+            "+model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default "
+            "model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=2 running.audio.max_len=256 "
+            "running.audio.num_mel_bins=64 running.batch_size=24 running.epochs=2 "
+            "running.synthetic_steps=2 running.save_epoch=False optimizer.warmup_epoch=1").split()
+    traj = {}
+    for mb in (0, 8):
+        cfg = compose(base + [f"running.micro_batch={mb}"])
+        cfg.rank = 0
+        torch.manual_seed(cfg.seed)
+        mon = VAMonitor(cfg, lambda *_: None, torch.device(DEV))
+        images, audios, _, _, _ = mon.make_batch(next(iter(mon.dataloader)))
+        with torch.no_grad():
+            before = float(mon.model(images, audios, None))              # fills the no-grad weight cache with the initial weights
+        losses = []
+        for i in range(3):
+            adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, i + 1)
+            losses.append(float(mon.step(images, audios, None).detach()))
+            with torch.no_grad():
+                after = float(mon.model(images, audios, None))
+            recorded = float(mon.model(images, audios, None).detach())
+            assert after == recorded, (mb, i, after, recorded)
+        assert abs(losses[0] - before) < 1e-6 and after != before, (before, losses, after)
+        traj[mb] = losses
+    for a, b in zip(traj[0], traj[8]):
+        assert abs(a - b) < 2e-5, (traj[0], traj[8])
+
+
 def test_e4m3_step_under_the_activation_memory_plans():
     """`running.fp8_gemm` through the trainer (VAMonitor.step): the loss stays within the e4m3 noise of the bf16 step, recompute is
     bit-identical, micro-batching equal up to fp32 summation order -- the three switches of the configs[4] bench leg together."""

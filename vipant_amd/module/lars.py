@@ -75,3 +75,8 @@ class LARS(torch.optim.Optimizer):
                 st["mu"] = mu
             self._fused_key = key
         self._fused.step(glist, lrs, g0["weight_decay"], g0["momentum"], g0["eta"])
+        # the kernel wrote the parameters through raw pointers: tell torch, so that everything keyed on a tensor's version sees the
+        # update -- above all the bf16 weight cache of no-grad forwards (evaluation between epochs, the feature pass of
+        # `running.micro_batch`), which would otherwise keep serving the weights of the first step it saw
+        for p in plist:
+            torch.autograd.graph.increment_version(p)
