@@ -118,7 +118,7 @@ int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream
 /* fp8 operands (BASELINE.json configs[4], "fp8 MFMA weights"; the reference has no counterpart -- its contractions are the
  * fp16 autocast matmuls of clip/model.py:170-187 -- so parity is against an exact emulation of this quantiser, tests/test_fp8_gpu.py).
  * bf16 rows x [M, K] -> OCP e4m3 rows q [M, K] with one power-of-two scale per row: scale[m] = e + 127 where e is the smallest
- * exponent with max|x[m, :]| / 2^e <= 448, q = round-to-nearest-even(x / 2^e).  K % 8 == 0, K <= 4096. */
+ * exponent with max|x[m, :]| / 2^e <= 448, q = round-to-nearest-even(x / 2^e).  K % 8 == 0, K <= 8192. */
 int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
                                void* stream);
 /* C[M, N] (bf16) = (A 2^(sa - 127)) (B 2^(sb - 127))^T (+ bias), A [M, K] and B [N, K] e4m3 with the row scales above, on

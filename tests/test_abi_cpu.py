@@ -63,8 +63,8 @@ def test_bad_arguments_are_reported_not_executed():
         _ffi.call("vipant_gemm_nt_e4m3", 16, 192, 16, 16, 192, 16, 16, 64, None, None, 4, 64, 192, 0, None)
     with pytest.raises(_ffi.VipantError, match="row scales"):
         _ffi.call("vipant_gemm_nt_e4m3", 16, 256, None, 16, 256, 16, 16, 64, None, None, 4, 64, 256, 0, None)
-    with pytest.raises(_ffi.VipantError, match="K <= 4096"):
-        _ffi.call("vipant_quant_e4m3_rows", 16, 8192, 16, 8192, 16, 4, 8192, None)
+    with pytest.raises(_ffi.VipantError, match="K <= 8192"):
+        _ffi.call("vipant_quant_e4m3_rows", 16, 16384, 16, 16384, 16, 4, 16384, None)
     with pytest.raises(_ffi.VipantError, match="go together"):
         _ffi.call("vipant_layernorm_fwd_e4m3", 16, 768, 16, 16, 16, None, 16, 16, 4, 768, None, None, 16, None, None)
 

@@ -36,7 +36,7 @@ def dequant(q_u8, s_u8):
     return q_u8.view(torch.float8_e4m3fn).float() * torch.exp2(s_u8.float() - 127)[:, None]
 
 
-@pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096)])
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096), (33, 5120), (17, 8192)])
 def test_quantiser_matches_the_stated_format(ops, M, K):
     rows = torch.exp2(torch.randint(-12, 12, (M, 1), device=DEV).float())                 # row magnitudes over 24 octaves
     x = (rnd(M, K, seed=M + K) * rows).to(torch.bfloat16)

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __re
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,
                                           int64_t K, void* stream) {
-    VIPANT_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= 4096, VIPANT_EBADSHAPE, "quant_e4m3_rows: need K %% 8 == 0 and K <= 4096 (M=%ld K=%ld)",
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= 8192, VIPANT_EBADSHAPE, "quant_e4m3_rows: need K %% 8 == 0 and K <= 8192 (M=%ld K=%ld)",
                    (long)M, (long)K);
     VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0, VIPANT_EALIGN,
                    "quant_e4m3_rows: misaligned rows");
@@ -399,9 +399,10 @@ extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_
     case NV: hipLaunchKernelGGL(quant_e4m3_rows_kernel<NV>, grid, block, 0, st, (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K); break;
     switch ((int)ceil_div(K, 512)) {
         VIPANT_QUANT_CASE(1) VIPANT_QUANT_CASE(2) VIPANT_QUANT_CASE(3) VIPANT_QUANT_CASE(4) VIPANT_QUANT_CASE(5) VIPANT_QUANT_CASE(6)
-        VIPANT_QUANT_CASE(7) VIPANT_QUANT_CASE(8)
+        VIPANT_QUANT_CASE(7) VIPANT_QUANT_CASE(8) VIPANT_QUANT_CASE(9) VIPANT_QUANT_CASE(10) VIPANT_QUANT_CASE(11) VIPANT_QUANT_CASE(12)
+        VIPANT_QUANT_CASE(13) VIPANT_QUANT_CASE(14) VIPANT_QUANT_CASE(15) VIPANT_QUANT_CASE(16)
         default:
-            vipant_set_error("quant_e4m3_rows: rows longer than 4096 elements are not built (K=%ld)", (long)K);
+            vipant_set_error("quant_e4m3_rows: rows longer than 8192 elements are not built (K=%ld)", (long)K);
             return VIPANT_EBADSHAPE;
     }
 #undef VIPANT_QUANT_CASE
