@@ -11,6 +11,8 @@ functions (oracle/ref_cpu.py) with rounding points inserted:
                                                  with 3 more mantissa bits: clip/model.py:157-160, cvap/module/val.py:253-257)
   D  B + bf16 GRADIENT stream only            -- forward as B (loss and features unchanged); the gradient of the residual
                                                  stream is rounded to bf16 after every residual-gradient add
+  E  D + fp16 FORWARD stream                  -- x <- fp16(x + branch) after every residual add: the reference's own autocast
+                                                 stream precision (clip/model.py:157-160), LayerNorm statistics in fp32
 Usage: python tools/stream_precision_study.py [b] [T] [F] [layers]
 Results are recorded in profiles/r2_stream_precision.md.
 """
@@ -38,6 +40,16 @@ class _Round(torch.autograd.Function):
         return (g.bfloat16().float() if ctx.bwd else g), None
 
 
+class _RoundF16(torch.autograd.Function):    # forward rounded to fp16 (the reference's autocast stream), gradient to bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 class _RoundBwd(torch.autograd.Function):       # forward untouched, gradient rounded to bf16
     @staticmethod
     def forward(ctx, x):
@@ -51,6 +63,8 @@ class _RoundBwd(torch.autograd.Function):       # forward untouched, gradient ro
 def rnd(x, on=True, bwd=True):
     if on == "grad":
         return _RoundBwd.apply(x)
+    if on == "f16":
+        return _RoundF16.apply(x)
     return _Round.apply(x, bwd) if on else x
 
 
@@ -98,7 +112,8 @@ def main():
     img = R.l2_normalize(gen.det_randn("study/img", (b, 512)))
     out = {}
     for name, q, qs in (("A fp32", False, False), ("B bf16 operands, fp32 stream", True, False), ("C bf16 operands, bf16 stream", True, True),
-                        ("D bf16 operands, fp32 stream, bf16 GRADIENT stream", True, "grad")):
+                        ("D bf16 operands, fp32 stream, bf16 GRADIENT stream", True, "grad"),
+                        ("E bf16 operands, fp16 stream (fp32 LN statistics), bf16 GRADIENT stream", True, "f16")):
         sd = {k: v.clone().requires_grad_() for k, v in w.items()}
         ls = torch.tensor(2.6592600, requires_grad=True)
         feat = tower(aud, sd, L, stride, pr, q, qs)

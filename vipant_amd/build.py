@@ -23,7 +23,12 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # per-file additions.  gemm_nt.hip: the e4m3 K-loop has no dependency between the MFMAs of its two barrier intervals, and LLVM's
 # machine sinker moves all 32 of a K-tile below both barriers (into the loop latch), which undoes the ping-pong schedule and
 # spills 25 registers: 1.18 -> 1.69 PFLOP/s at K = 1024 with the pass off; the bf16 kernels of the file compile to the same code.
-EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink"]}
+# attention.hip: the single-pass backward runs one wave per SIMD with 512 registers; for such kernels LLVM selects every MFMA with an
+# AGPR destination, and each S / dP score then costs a v_accvgpr_read before the VALU can touch it (180 of 400 VALU instructions per
+# step, and the kernel is VALU-issue bound).  With the VGPR form forced, accumulators land where the arithmetic needs them and the
+# resident operand fragments take the AGPRs (pinned there by "+a" constraints in the source); the two-waves-per-SIMD kernels of the
+# file were VGPR-form already.
+EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 _REMARK_ECHO = re.compile(r"^\s*(\d+ \||\|)")      # the source-line echo clang prints under each remark
