@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--fp8", action="store_true", help="running.fp8_gemm: e4m3 operands in the audio tower's NT contractions "
                                                        "(BASELINE.json configs[4]; never the headline line, which is bf16)")
     ap.add_argument("--micro-batch", type=int, default=0, help="running.micro_batch: towers in micro-batches under one loss")
+    ap.add_argument("--stream", choices=["fp32", "fp16"], default=None,
+                    help="running.stream_dtype: precision of the residual stream inside the transformer stacks (default: the "
+                         "framework's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
@@ -200,6 +203,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
           f"running.imagine=False model.loss.va=False model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} +running.negatives=local "
           f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
+          + (f"running.stream_dtype={args.stream} " if args.stream else "") +
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
           f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -285,6 +289,7 @@ def main():
           f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} "
           f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
+          + (f"running.stream_dtype={args.stream} " if args.stream else "") +
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} "
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()

@@ -79,8 +79,13 @@ int32_t vipant_colsum_bf16(const uint16_t* X, int64_t ldx, float* out, int64_t M
 int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y,
                              float* y_f32, float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add,
                              float* sum_out, void* stream);
-/* out fp32 [M, D] = x fp32 + add bf16 (the last block's residual add, no norm behind it). */
-int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int64_t n, void* stream);
+/* Precision of the residual stream INSIDE the transformer stack (`stream_flags` of the operators below): fp32, or fp16 -- the
+ * reference's own autocast precision (clip/model.py:157-160 casts the fp32 LayerNorm result back to the fp16 stream) -- with fp32
+ * statistics and the norm taken on the unrounded sum.  IN: the `x` argument is fp16; OUT: the `x_out` / `sum_out` argument is. */
+#define VIPANT_STREAM_IN_F16 1
+#define VIPANT_STREAM_OUT_F16 2
+/* out fp32 [M, D] = x (fp32, or fp16 with VIPANT_STREAM_IN_F16) + add bf16 (the last block's residual add, no norm behind it). */
+int32_t vipant_residual_add(const void* x, const uint16_t* add, float* out, int64_t n, int32_t stream_flags, void* stream);
 /* dx[M,D] = dres (optional residual-stream gradient) + LN'(dy); outputs dx_f32 (optional) and dx_bf16 (optional).
  * flags: VIPANT_LN_DY_F32 -- dy is fp32 [M,D] (else bf16); VIPANT_LN_DRES_BF16 -- dres is bf16 [M,D] (row stride D; may be the
  * same buffer as dx_bf16), else fp32 with row stride lddx (may alias dx_f32).  dgamma / dbeta fp32 [D] (+)= column reductions;
@@ -89,7 +94,8 @@ int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int
 size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
 #define VIPANT_LN_DY_F32 1
 #define VIPANT_LN_DRES_BF16 2
-int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx, const float* mean,
+#define VIPANT_LN_X_F16 4 /* x rows are fp16 (a saved fp16 stream) */
+int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const void* x, int64_t ldx, const float* mean,
                              const float* rstd, const float* gamma, const void* dres, float* dx_f32, int64_t lddx,
                              uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int32_t accumulate,
                              int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream);
@@ -281,37 +287,37 @@ typedef struct vipant_fp8_plan {
 } vipant_fp8_plan;
 /* LayerNorm with the row quantisation of its bf16 output fused (the row is in registers anyway): q bytes [M, D] / qscale bytes [M]
  * = vipant_quant_e4m3_rows of y resp. dx_bf16, bit for bit; both NULL: exactly vipant_layernorm_fwd / vipant_layernorm_bwd. */
-int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y, float* y_f32,
-                                  float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add, float* sum_out, uint8_t* q,
-                                  uint8_t* qscale, void* stream);
-int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const float* x, int64_t ldx, const float* mean, const float* rstd,
+int32_t vipant_layernorm_fwd_e4m3(const void* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y, float* y_f32,
+                                  float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add, void* sum_out, uint8_t* q,
+                                  uint8_t* qscale, int32_t stream_flags, void* stream);
+int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const void* x, int64_t ldx, const float* mean, const float* rstd,
                                   const float* gamma, const void* dres, float* dx_f32, int64_t lddx, uint16_t* dx_bf16,
                                   float* dgamma, float* dbeta, float* dx_colsum, int32_t accumulate, int64_t M, int64_t D,
                                   void* workspace, size_t workspace_bytes, uint8_t* q, uint8_t* qscale, void* stream);
-int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+int32_t vipant_ln_qkv_fwd_e4m3(const void* x, const uint16_t* add, void* x_out, const float* gamma, const float* beta,
                                const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd, uint16_t* qkv,
-                               int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream);
-int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x, const float* mean,
+                               int64_t M, int64_t D, const vipant_fp8_plan* plan, int32_t stream_flags, void* stream);
+int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const void* x, const float* mean,
                                const float* rstd, const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* dh, float* dw,
                                float* db, float* dgamma, float* dbeta, float* dx_colsum, int64_t M, int64_t D, void* workspace,
-                               size_t workspace_bytes, const vipant_fp8_plan* plan, void* stream);
+                               size_t workspace_bytes, const vipant_fp8_plan* plan, int32_t stream_flags, void* stream);
 int32_t vipant_gemm_bias_residual_fwd_e4m3(const uint16_t* a, const uint16_t* w, const float* bias, const float* residual, void* out,
                                            int64_t M, int64_t N, int64_t K, const vipant_fp8_plan* plan, void* stream);
 int32_t vipant_gemm_bias_residual_bwd_e4m3(const uint16_t* dy, const uint16_t* w_t, const uint16_t* a, uint16_t* da, float* dw,
                                            int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
                                            const vipant_fp8_plan* plan, void* stream);
-int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const void* x, const uint16_t* add, void* x_out, const float* gamma, const float* beta,
                                          const uint16_t* w_fc, const float* b_fc, const uint16_t* w_proj, const float* b_proj,
                                          uint16_t* h, float* mean, float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M,
-                                         int64_t D, const vipant_fp8_plan* plan, void* stream);
+                                         int64_t D, const vipant_fp8_plan* plan, int32_t stream_flags, void* stream);
 int32_t vipant_mlp_quickgelu_recompute_e4m3(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode, uint16_t* g,
                                             int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream);
 int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t, const uint8_t* dcode,
-                                         const uint16_t* g, const uint16_t* h, const float* x, const float* mean, const float* rstd,
+                                         const uint16_t* g, const uint16_t* h, const void* x, const float* mean, const float* rstd,
                                          const float* gamma, float* dstream, uint16_t* dx_bf16, uint16_t* du, uint16_t* dh,
                                          float* dw_proj, float* dw_fc, float* db_fc, float* dgamma, float* dbeta, float* dx_colsum,
                                          int64_t M, int64_t D, void* workspace, size_t workspace_bytes, const vipant_fp8_plan* plan,
-                                         void* stream);
+                                         int32_t stream_flags, void* stream);
 
 /* K1 -- ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + contraction, cls token, positional table,
  * ln_pre.  x fp32 [b,C,T,F]; conv_w fp32 [Dw,Cw,ph,pw] (mean_channels != 0: the Cw stored channels are averaged, val.py:236-244);

@@ -66,7 +66,7 @@ def test_bad_arguments_are_reported_not_executed():
     with pytest.raises(_ffi.VipantError, match="K <= 8192"):
         _ffi.call("vipant_quant_e4m3_rows", 16, 16384, 16, 16384, 16, 4, 16384, None)
     with pytest.raises(_ffi.VipantError, match="go together"):
-        _ffi.call("vipant_layernorm_fwd_e4m3", 16, 768, 16, 16, 16, None, 16, 16, 4, 768, None, None, 16, None, None)
+        _ffi.call("vipant_layernorm_fwd_e4m3", 16, 768, 16, 16, 16, None, 16, 16, 4, 768, None, None, 16, None, 0, None)
 
 
 def test_no_cpu_fallback():

@@ -161,7 +161,7 @@ def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
     qs = torch.empty(M, dtype=torch.uint8, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     ops.call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, mean.data_ptr(),
-             rstd.data_ptr(), M, D, add.data_ptr(), xs.data_ptr(), q.data_ptr(), qs.data_ptr(), st)
+             rstd.data_ptr(), M, D, add.data_ptr(), xs.data_ptr(), q.data_ptr(), qs.data_ptr(), 0, st)
     q_ref, s_ref = ops.quant_e4m3(y)
     assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
     y_plain = ops.layernorm_fwd(x, gamma, beta, add=add, want_sum=True)[0]

@@ -260,6 +260,37 @@ def test_layernorm(ops, M, D):
     assert_close(dx, xr.grad, 1e-4, 1e-4, "ln bwd dx (f32 dy)")
 
 
+def test_layernorm_fp16_stream(ops):
+    """`running.stream_dtype: fp16`: the stream read / written as fp16, statistics in fp32, the norm taken on the unrounded sum."""
+    M, D = 300, 768
+    x = (rnd(M, D, seed=11) * 3).to(torch.float16)
+    add = rnd(M, D, seed=12).to(torch.bfloat16)
+    gm, bt = rnd(D, seed=13) * 0.1 + 1.0, rnd(D, seed=14) * 0.1
+    h, _, mean, rstd, xs = ops.layernorm_fwd(x, gm, bt, add=add, want_sum=True, sum_f16=True)
+    assert xs.dtype == torch.float16
+    s64 = x.double() + add.double()
+    assert torch.equal(xs, s64.float().to(torch.float16)), "the stored stream is the fp16 rounding of the exact sum"
+    ref = torch.nn.functional.layer_norm(s64, (D,), gm.double(), bt.double(), 1e-5)
+    assert_close(h, ref, 1e-2, 1e-2, "ln fwd (fp16 stream)")
+    assert_close(mean, s64.mean(-1), 1e-5, 1e-5, "ln mean (fp16 stream)")
+    # fp16 in, fp32 out and fp32 in, fp16 out (the first / last pass of a stack)
+    xs32 = ops.layernorm_fwd(x, gm, bt, add=add, want_sum=True)[4]
+    assert xs32.dtype == torch.float32 and torch.equal(xs32, s64.float())
+    xs16 = ops.layernorm_fwd(x.float(), gm, bt, add=add, want_sum=True, sum_f16=True)[4]
+    assert torch.equal(xs16, xs)
+    assert_close(ops.residual_add(x, add), s64, 1e-6, 1e-6, "residual_add (fp16 stream)")
+    # backward on the saved fp16 rows
+    xr = xs.double().requires_grad_()
+    dy = rnd(M, D, seed=15, dtype=torch.bfloat16)
+    gmr = gm.double().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (D,), gmr, bt.double(), 1e-5).backward(dy.double())
+    _, _, mean2, rstd2 = ops.layernorm_fwd(xs, gm, bt)
+    dx = torch.empty(M, D, device=DEV); dg = torch.empty(D, device=DEV); db = torch.empty(D, device=DEV)
+    ops.layernorm_bwd(dy, xs, mean2, rstd2, gm, dx=dx, dgamma=dg, dbeta=db)
+    assert_close(dx, xr.grad, 1e-4, 1e-4, "ln bwd dx (fp16 rows)")
+    assert_close(dg, gmr.grad, 1e-4, 1e-3 * math.sqrt(M), "ln bwd dgamma (fp16 rows)")
+
+
 # ------------------------------------------------------------------------------------------ attention
 def ref_attention(qkv, batch, S, H, causal):
     D = H * 64

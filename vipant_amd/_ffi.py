@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIPANT_HIP_LIB") or os.path.join(_HERE, "lib", "libvipant_hip.so")   # override: A/B timing of builds
 
 EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32, EPI_QUICKGELU_D8, EPI_DQUICKGELU_D8 = range(8)
+STREAM_IN_F16, STREAM_OUT_F16 = 1, 2          # VIPANT_STREAM_*: precision of the residual stream inside the transformer stack
+LN_DY_F32, LN_DRES_BF16, LN_X_F16 = 1, 2, 4
 
 _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 
@@ -38,9 +40,9 @@ PROTOTYPES = {
     "vipant_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_colsum_bf16": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _sz, _p]),
     "vipant_layernorm_fwd": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p]),
-    "vipant_residual_add": (_i32, [_p, _p, _p, _i64, _p]),
+    "vipant_residual_add": (_i32, [_p, _p, _p, _i64, _i32, _p]),
     "vipant_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
-    "vipant_layernorm_fwd_e4m3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "vipant_layernorm_fwd_e4m3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _p]),
     "vipant_layernorm_bwd_e4m3": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p, _p, _p]),
     "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
@@ -69,13 +71,13 @@ PROTOTYPES = {
     # fused operator set (vipant_amd/csrc/block.hip)
     "vipant_block_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_ln_qkv_fwd": (_i32, [_p] * 11 + [_i64, _i64, _p]),
-    "vipant_ln_qkv_fwd_e4m3": (_i32, [_p] * 11 + [_i64, _i64, _p, _p]),
-    "vipant_ln_qkv_bwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p, _p]),
+    "vipant_ln_qkv_fwd_e4m3": (_i32, [_p] * 11 + [_i64, _i64, _p, _i32, _p]),
+    "vipant_ln_qkv_bwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p, _i32, _p]),
     "vipant_gemm_bias_residual_fwd_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _p]),
     "vipant_gemm_bias_residual_bwd_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _sz, _p, _p]),
-    "vipant_ln_mlp_quickgelu_fwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _p]),
+    "vipant_ln_mlp_quickgelu_fwd_e4m3": (_i32, [_p] * 15 + [_i64, _i64, _p, _i32, _p]),
     "vipant_mlp_quickgelu_recompute_e4m3": (_i32, [_p] * 5 + [_i64, _i64, _p, _p]),
-    "vipant_ln_mlp_quickgelu_bwd_e4m3": (_i32, [_p] * 20 + [_i64, _i64, _p, _sz, _p, _p]),
+    "vipant_ln_mlp_quickgelu_bwd_e4m3": (_i32, [_p] * 20 + [_i64, _i64, _p, _sz, _p, _i32, _p]),
     "vipant_ln_qkv_bwd": (_i32, [_p] * 15 + [_i64, _i64, _p, _sz, _p]),
     "vipant_gemm_bias_residual_fwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p]),
     "vipant_gemm_bias_residual_bwd": (_i32, [_p] * 5 + [_i64, _i64, _i64, _p, _sz, _p]),

@@ -39,15 +39,16 @@ int32_t nt(const vipant_fp8_plan* plan, const uint8_t* wq, const uint8_t* ws, co
 
 // LayerNorm backward of a block operator: in place on the stream gradient (fp32 master + bf16 copy, or bf16 only), the new
 // gradient's quantised form written beside it when the plan carries the buffers
-int32_t ln_bwd(const vipant_fp8_plan* plan, const uint16_t* dh, const float* x, const float* mean, const float* rstd,
-               const float* gamma, float* dstream, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
-               int64_t D, void* workspace, size_t workspace_bytes, void* stream) {
+int32_t ln_bwd(const vipant_fp8_plan* plan, const uint16_t* dh, const void* x, int32_t stream_flags, const float* mean,
+               const float* rstd, const float* gamma, float* dstream, uint16_t* dx_bf16, float* dgamma, float* dbeta,
+               float* dx_colsum, int64_t M, int64_t D, void* workspace, size_t workspace_bytes, void* stream) {
     uint8_t* q = plan ? plan->dy_q : nullptr;
     uint8_t* qs = plan ? plan->dy_scale : nullptr;
+    const int32_t xf = (stream_flags & VIPANT_STREAM_IN_F16) ? VIPANT_LN_X_F16 : 0;       // the saved stream rows are fp16
     if (dstream == nullptr)
-        return vipant_layernorm_bwd_e4m3(dh, VIPANT_LN_DRES_BF16, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma,
+        return vipant_layernorm_bwd_e4m3(dh, VIPANT_LN_DRES_BF16 | xf, x, D, mean, rstd, gamma, dx_bf16, nullptr, D, dx_bf16, dgamma,
                                          dbeta, dx_colsum, 0, M, D, workspace, workspace_bytes, q, qs, stream);
-    return vipant_layernorm_bwd_e4m3(dh, 0, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
+    return vipant_layernorm_bwd_e4m3(dh, xf, x, D, mean, rstd, gamma, dstream, dstream, D, dx_bf16, dgamma, dbeta, dx_colsum, 0, M,
                                      D, workspace, workspace_bytes, q, qs, stream);
 }
 
@@ -62,13 +63,14 @@ extern "C" size_t vipant_block_workspace_bytes(int64_t M, int64_t D) {
 }
 
 // ------------------------------------------------------------------------------------------------ K2: ln_1 + in_proj
-extern "C" int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
+extern "C" int32_t vipant_ln_qkv_fwd_e4m3(const void* x, const uint16_t* add, void* x_out, const float* gamma, const float* beta,
                                           const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd,
-                                          uint16_t* qkv, int64_t M, int64_t D, const vipant_fp8_plan* plan, void* stream) {
+                                          uint16_t* qkv, int64_t M, int64_t D, const vipant_fp8_plan* plan, int32_t stream_flags,
+                                          void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_qkv_fwd: add and x_out go together");
     TRY(vipant_layernorm_fwd_e4m3(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, plan ? plan->act_q : nullptr,
-                                  plan ? plan->act_scale : nullptr, stream));
+                                  plan ? plan->act_scale : nullptr, stream_flags, stream));
     return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
               plan ? plan->act_scale : nullptr, h, w_qkv, qkv, b_qkv, nullptr, M, 3 * D, D, VIPANT_EPI_BF16, stream);
 }
@@ -76,14 +78,14 @@ extern "C" int32_t vipant_ln_qkv_fwd_e4m3(const float* x, const uint16_t* add, f
 extern "C" int32_t vipant_ln_qkv_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma, const float* beta,
                                      const uint16_t* w_qkv, const float* b_qkv, uint16_t* h, float* mean, float* rstd,
                                      uint16_t* qkv, int64_t M, int64_t D, void* stream) {
-    return vipant_ln_qkv_fwd_e4m3(x, add, x_out, gamma, beta, w_qkv, b_qkv, h, mean, rstd, qkv, M, D, nullptr, stream);
+    return vipant_ln_qkv_fwd_e4m3(x, add, x_out, gamma, beta, w_qkv, b_qkv, h, mean, rstd, qkv, M, D, nullptr, 0, stream);
 }
 
-extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x,
+extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const void* x,
                                           const float* mean, const float* rstd, const float* gamma, float* dstream,
                                           uint16_t* dx_bf16, uint16_t* dh, float* dw, float* db, float* dgamma, float* dbeta,
                                           float* dx_colsum, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
-                                          const vipant_fp8_plan* plan, void* stream) {
+                                          const vipant_fp8_plan* plan, int32_t stream_flags, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE, "ln_qkv_bwd: workspace too small");
     // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D])
@@ -92,7 +94,8 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
     TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
     // ln_1 backward + residual-gradient add, in place on the stream gradient (fp32 master + bf16 copy, or bf16 only)
-    return ln_bwd(plan, dh, x, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, stream);
+    return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,
+                  workspace_bytes, stream);
 }
 
 extern "C" int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv_t, const uint16_t* h, const float* x,
@@ -101,7 +104,7 @@ extern "C" int32_t vipant_ln_qkv_bwd(const uint16_t* dqkv, const uint16_t* w_qkv
                                      float* dx_colsum, int64_t M, int64_t D, void* workspace, size_t workspace_bytes,
                                      void* stream) {
     return vipant_ln_qkv_bwd_e4m3(dqkv, w_qkv_t, h, x, mean, rstd, gamma, dstream, dx_bf16, dh, dw, db, dgamma, dbeta, dx_colsum, M,
-                                  D, workspace, workspace_bytes, nullptr, stream);
+                                  D, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ K4: out_proj
@@ -142,15 +145,15 @@ extern "C" int32_t vipant_gemm_bias_residual_bwd(const uint16_t* dy, const uint1
 }
 
 // ------------------------------------------------------------------------------------------------ K5: ln_2 + MLP
-extern "C" int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const float* x, const uint16_t* add, float* x_out, const float* gamma,
+extern "C" int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const void* x, const uint16_t* add, void* x_out, const float* gamma,
                                                     const float* beta, const uint16_t* w_fc, const float* b_fc,
                                                     const uint16_t* w_proj, const float* b_proj, uint16_t* h, float* mean,
                                                     float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M, int64_t D,
-                                                    const vipant_fp8_plan* plan, void* stream) {
+                                                    const vipant_fp8_plan* plan, int32_t stream_flags, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: add and x_out go together");
     TRY(vipant_layernorm_fwd_e4m3(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, plan ? plan->act_q : nullptr,
-                                  plan ? plan->act_scale : nullptr, stream));
+                                  plan ? plan->act_scale : nullptr, stream_flags, stream));
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
            plan ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream));
     return nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, g, w_proj, y, b_proj, nullptr, M,
@@ -163,7 +166,7 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* a
                                                float* rstd, uint8_t* dcode, uint16_t* g, uint16_t* y, int64_t M, int64_t D,
                                                void* stream) {
     return vipant_ln_mlp_quickgelu_fwd_e4m3(x, add, x_out, gamma, beta, w_fc, b_fc, w_proj, b_proj, h, mean, rstd, dcode, g, y, M, D,
-                                            nullptr, stream);
+                                            nullptr, 0, stream);
 }
 
 // The [M, 4D] activations (QuickGELU' codes, g) alone, from the saved LayerNorm output (`running.recompute_mlp`: they were not kept).
@@ -180,12 +183,12 @@ extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint1
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t,
-                                                    const uint8_t* dcode, const uint16_t* g, const uint16_t* h, const float* x,
+                                                    const uint8_t* dcode, const uint16_t* g, const uint16_t* h, const void* x,
                                                     const float* mean, const float* rstd, const float* gamma, float* dstream,
                                                     uint16_t* dx_bf16, uint16_t* du, uint16_t* dh, float* dw_proj, float* dw_fc,
                                                     float* db_fc, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
                                                     int64_t D, void* workspace, size_t workspace_bytes, const vipant_fp8_plan* plan,
-                                                    void* stream) {
+                                                    int32_t stream_flags, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_mlp_quickgelu_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE,
                    "ln_mlp_quickgelu_bwd: workspace too small");
@@ -200,7 +203,8 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
            4 * D, VIPANT_EPI_BF16, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
-    return ln_bwd(plan, dh, x, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, stream);
+    return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,
+                  workspace_bytes, stream);
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t, const uint16_t* w_fc_t,
@@ -210,7 +214,7 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_
                                                float* db_fc, float* dgamma, float* dbeta, float* dx_colsum, int64_t M,
                                                int64_t D, void* workspace, size_t workspace_bytes, void* stream) {
     return vipant_ln_mlp_quickgelu_bwd_e4m3(dy, w_proj_t, w_fc_t, dcode, g, h, x, mean, rstd, gamma, dstream, dx_bf16, du, dh, dw_proj,
-                                            dw_fc, db_fc, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, nullptr, stream);
+                                            dw_fc, db_fc, dgamma, dbeta, dx_colsum, M, D, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ K1: patch embedding + ln_pre

@@ -104,11 +104,20 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(CastMulti a) {
     }
 }
 
-__global__ __launch_bounds__(256) void residual_add_kernel(const float* __restrict__ x, const bf16_t* __restrict__ add,
+template <typename XT>
+__global__ __launch_bounds__(256) void residual_add_kernel(const XT* __restrict__ x, const bf16_t* __restrict__ add,
                                                            float* __restrict__ out, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const bf16x4 a = *(const bf16x4*)(add + i * 4);
-        *(f32x4*)(out + i * 4) = *(const f32x4*)(x + i * 4) + f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+        f32x4 v;
+        if constexpr (sizeof(XT) == 4) {
+            v = *(const f32x4*)(x + i * 4);
+        } else {
+            typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+            const f16x4_t h = *(const f16x4_t*)(x + i * 4);
+            v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        *(f32x4*)(out + i * 4) = v + f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
     }
 }
 
@@ -446,10 +455,14 @@ extern "C" int32_t vipant_cast_bf16_multi(const float* const* src, uint16_t* con
     return VIPANT_OK;
 }
 
-extern "C" int32_t vipant_residual_add(const float* x, const uint16_t* add, float* out, int64_t n, void* stream) {
+extern "C" int32_t vipant_residual_add(const void* x, const uint16_t* add, float* out, int64_t n, int32_t stream_flags, void* stream) {
     VIPANT_REQUIRE(n > 0 && n % 4 == 0, VIPANT_EBADSHAPE, "residual_add: numel must be a positive multiple of 4");
-    hipLaunchKernelGGL(residual_add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       (const bf16_t*)add, out, n / 4);
+    if (stream_flags & VIPANT_STREAM_IN_F16)
+        hipLaunchKernelGGL(residual_add_kernel<_Float16>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)x, (const bf16_t*)add, out, n / 4);
+    else
+        hipLaunchKernelGGL(residual_add_kernel<float>, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (const bf16_t*)add, out, n / 4);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

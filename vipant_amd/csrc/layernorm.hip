@@ -7,6 +7,21 @@ namespace {
 
 constexpr float LN_EPS = 1e-5f;
 
+// The residual stream is fp32 or fp16 (the reference's own autocast precision, clip/model.py:157-160); statistics are fp32 always.
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_stream4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load_stream4(const f16_t* p) {
+    const f16x4 h = *(const f16x4*)p;
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void store_stream4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void store_stream4(f16_t* p, f32x4 v) {
+    f16x4 h;
+    h[0] = (f16_t)v[0]; h[1] = (f16_t)v[1]; h[2] = (f16_t)v[2]; h[3] = (f16_t)v[3];
+    *(f16x4*)p = h;
+}
+
 // Row quantiser of vipant_quant_e4m3_rows (elementwise.hip) on a row that is already in registers, four consecutive elements per
 // lane and 256-column step: the values are first rounded to bf16, so the bytes and the scale are those the stand-alone kernel
 // produces from the bf16 tensor this kernel also writes.
@@ -38,13 +53,13 @@ __device__ __forceinline__ void quant_row_e4m3(f32x4 (&o)[NV], uint8_t* __restri
     }
 }
 
-template <int NV>  // D = NV * 256
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+template <int NV, typename XI, typename XO>  // D = NV * 256; XI / XO: the stream's element type on the way in / out
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int64_t M,
-                                                     const bf16_t* __restrict__ add, float* __restrict__ sum_out,
+                                                     const bf16_t* __restrict__ add, XO* __restrict__ sum_out,
                                                      uint8_t* __restrict__ q8, uint8_t* __restrict__ q8s) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
@@ -57,16 +72,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         bv[t] = *(const f32x4*)(beta + (t * 64 + lane) * 4);
     }
     for (int64_t row = wave; row < M; row += nwaves) {
-        const float* xr = x + row * ldx;
+        const XI* xr = x + row * ldx;
         f32x4 v[NV];
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            v[t] = *(const f32x4*)(xr + (t * 64 + lane) * 4);
+            v[t] = load_stream4(xr + (t * 64 + lane) * 4);
             if (add != nullptr) {      // residual add fused in front of the norm: v = x + branch (bf16)
                 const bf16x4 a4 = *(const bf16x4*)(add + row * D + (t * 64 + lane) * 4);
                 v[t] += f32x4{(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
-                if (sum_out != nullptr) *(f32x4*)(sum_out + row * D + (t * 64 + lane) * 4) = v[t];
+                // the new stream is stored in its own precision; the norm below works on the unrounded sum
+                if (sum_out != nullptr) store_stream4(sum_out + row * D + (t * 64 + lane) * 4, v[t]);
             }
             s += v[t][0] + v[t][1] + v[t][2] + v[t][3];
         }
@@ -95,8 +111,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Per-block partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to `partial` [grid, 2, D].
 // DRES_BF16: the residual-stream gradient is a bf16 [M, D] tensor (read here, may be the same buffer as dxb: a lane reads its
 // elements of a row before it writes them) instead of an fp32 one.
-template <int NV, bool DY_F32, bool DRES_BF16>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+template <int NV, bool DY_F32, bool DRES_BF16, typename XT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const XT* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const void* dres_, float* dx, int64_t lddx,
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 const bf16x4 b = *(const bf16x4*)((const bf16_t*)dy_ + row * D + col);
                 dyv = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
             }
-            xh[t] = (*(const f32x4*)(x + row * ldx + col) - mu) * rs;
+            xh[t] = (load_stream4(x + row * ldx + col) - mu) * rs;
             g[t] = dyv * gv[t];
             dg[t] += dyv * xh[t];
             db[t] += dyv;
@@ -202,19 +218,28 @@ int ln_blocks(int64_t M) {
 
 }  // namespace
 
-extern "C" int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const float* gamma, const float* beta,
+extern "C" int32_t vipant_layernorm_fwd_e4m3(const void* x, int64_t ldx, const float* gamma, const float* beta,
                                              uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
-                                             const uint16_t* add, float* sum_out, uint8_t* q, uint8_t* qscale, void* stream) {
+                                             const uint16_t* add, void* sum_out, uint8_t* q, uint8_t* qscale, int32_t stream_flags,
+                                             void* stream) {
     VIPANT_REQUIRE((q == nullptr) == (qscale == nullptr), VIPANT_EBADSHAPE, "layernorm_fwd: q and qscale go together");
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 256 == 0 && D <= 1024, VIPANT_EBADSHAPE,
                    "layernorm_fwd: D must be a multiple of 256 up to 1024 (D=%ld)", (long)D);
-    VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
+    const bool in16 = (stream_flags & VIPANT_STREAM_IN_F16) != 0, out16 = (stream_flags & VIPANT_STREAM_OUT_F16) != 0;
+    VIPANT_REQUIRE(ldx >= D && ldx % 4 == 0 && (uintptr_t)x % (in16 ? 8 : 16) == 0, VIPANT_EALIGN, "layernorm_fwd: bad ldx/alignment");
     hipStream_t s = (hipStream_t)stream;
     // one row per wave, no grid-stride loop: 254 us against 286 us with 2048 persistent workgroups at M = 161 792 (1.49 GB)
     const int blocks = (int)(ceil_div(M, 4) > (1 << 20) ? (1 << 20) : ceil_div(M, 4));
-#define LN_FWD(NV)                                                                                                   \
-    hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ldx, gamma, beta, (bf16_t*)y, y_f32, mean, \
-                       rstd, M, (const bf16_t*)add, sum_out, q, qscale)
+#define LN_FWD_T(NV, XI, XO)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<NV, XI, XO>), dim3(blocks), dim3(256), 0, s, (const XI*)x, ldx, gamma, beta, (bf16_t*)y, \
+                       y_f32, mean, rstd, M, (const bf16_t*)add, (XO*)sum_out, q, qscale)
+#define LN_FWD(NV)                                                              \
+    do {                                                                        \
+        if (in16 && out16) LN_FWD_T(NV, f16_t, f16_t);                          \
+        else if (in16) LN_FWD_T(NV, f16_t, float);                              \
+        else if (out16) LN_FWD_T(NV, float, f16_t);                             \
+        else LN_FWD_T(NV, float, float);                                        \
+    } while (0)
     switch (D / 256) {
         case 1: LN_FWD(1); break;
         case 2: LN_FWD(2); break;
@@ -222,6 +247,7 @@ extern "C" int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const 
         default: LN_FWD(4); break;
     }
 #undef LN_FWD
+#undef LN_FWD_T
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -229,14 +255,14 @@ extern "C" int32_t vipant_layernorm_fwd_e4m3(const float* x, int64_t ldx, const 
 extern "C" int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                         uint16_t* y, float* y_f32, float* mean, float* rstd, int64_t M, int64_t D,
                                         const uint16_t* add, float* sum_out, void* stream) {
-    return vipant_layernorm_fwd_e4m3(x, ldx, gamma, beta, y, y_f32, mean, rstd, M, D, add, sum_out, nullptr, nullptr, stream);
+    return vipant_layernorm_fwd_e4m3(x, ldx, gamma, beta, y, y_f32, mean, rstd, M, D, add, sum_out, nullptr, nullptr, 0, stream);
 }
 
 extern "C" size_t vipant_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
     return (size_t)ln_blocks(M) * 3 * (size_t)D * sizeof(float);
 }
 
-extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const float* x, int64_t ldx,
+extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, const void* x, int64_t ldx,
                                              const float* mean, const float* rstd, const float* gamma, const void* dres,
                                              float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
                                              float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,
@@ -253,17 +279,15 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
     const bool dy_is_f32 = (flags & VIPANT_LN_DY_F32) != 0, dres_bf16 = (flags & VIPANT_LN_DRES_BF16) != 0;
     VIPANT_REQUIRE(!(dres_bf16 && (dres == nullptr || dy_is_f32)), VIPANT_EBADSHAPE,
                    "layernorm_bwd: a bf16 residual gradient needs dres and a bf16 dy");
+    const bool x16 = (flags & VIPANT_LN_X_F16) != 0;
+#define LN_BWD_T(NV, A, B, XT)                                                                                                 \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, A, B, XT>), dim3(blocks), dim3(256), 0, s, dy, (const XT*)x, ldx, mean, rstd, gamma, dres, \
+                       dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale)
 #define LN_BWD(NV)                                                                                                   \
     do {                                                                                                             \
-        if (dy_is_f32)                                                                                               \
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, true, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
-        else if (dres_bf16)                                                                                          \
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
-        else                                                                                                         \
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, false, false>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, mean, rstd, \
-                               gamma, dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale);                              \
+        if (dy_is_f32) { if (x16) LN_BWD_T(NV, true, false, f16_t); else LN_BWD_T(NV, true, false, float); }         \
+        else if (dres_bf16) { if (x16) LN_BWD_T(NV, false, true, f16_t); else LN_BWD_T(NV, false, true, float); }    \
+        else { if (x16) LN_BWD_T(NV, false, false, f16_t); else LN_BWD_T(NV, false, false, float); }                 \
     } while (0)
     switch (D / 256) {
         case 1: LN_BWD(1); break;
@@ -272,6 +296,7 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
         default: LN_BWD(4); break;
     }
 #undef LN_BWD
+#undef LN_BWD_T
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(1024), 0, s,
                        (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
@@ -279,7 +304,7 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
     return VIPANT_OK;
 }
 
-extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const float* x, int64_t ldx,
+extern "C" int32_t vipant_layernorm_bwd(const void* dy, int32_t flags, const void* x, int64_t ldx,
                                         const float* mean, const float* rstd, const float* gamma, const void* dres,
                                         float* dx_f32, int64_t lddx, uint16_t* dx_bf16, float* dgamma, float* dbeta,
                                         float* dx_colsum, int32_t accumulate, int64_t M, int64_t D, void* workspace,

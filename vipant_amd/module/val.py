@@ -322,6 +322,7 @@ class TransformerBackbone(MetaEncoder):
         self.grad_sync = None       # set by vipant_amd.parallel for data-parallel replicas
         self.recompute_mlp = False  # `running.recompute_mlp`: do not keep the [M, 4D] MLP activations for the backward
         self.fp8 = False            # `running.fp8_gemm`: e4m3 operands in the NT contractions of the trainable blocks (configs[4])
+        self.stream_f16 = True      # `running.stream_dtype` (fp16 | fp32): residual stream inside the stack in the reference's autocast precision
 
     def build_attention_mask(self):
         """Marker only: the -inf upper-triangular mask (val.py:484-491) is applied inside the attention kernel."""
@@ -333,5 +334,5 @@ class TransformerBackbone(MetaEncoder):
             raise ValueError(f"sequence length {S} exceeds ctx_len {self.ctx_len}")
         params = [p for blk in self.resblocks for p in blk.flat_params()]
         out = ops.BackboneFn.apply(x.reshape(b * S, D), b, S, self.causal, self.grad_sync, self.recompute_mlp, self.fp8,
-                                   *ops.no_tape(params))
+                                   self.stream_f16, *ops.no_tape(params))
         return out.view(b, S, D)

@@ -89,6 +89,12 @@ class Monitor(object):
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):
                     head.encoder.recompute_mlp = True
+        # the residual stream inside every transformer stack: fp16 (the reference's autocast precision; default) or fp32;
+        # LayerNorm statistics are fp32 either way
+        stream_f16 = str(cfg.running.get("stream_dtype", "fp16")).lower() in ("fp16", "float16", "half")
+        for head in (model.audio_head, model.image_head, model.text_head):
+            if head is not None and hasattr(head, "encoder"):
+                head.encoder.stream_f16 = stream_f16
         if cfg.running.get("fp8_gemm", False):      # BASELINE.json configs[4]: e4m3 operands in the audio tower's NT contractions
             if model.audio_head is not None and hasattr(model.audio_head, "encoder"):
                 model.audio_head.encoder.fp8 = True

@@ -20,7 +20,7 @@ from ._ffi import (EPI_BF16, EPI_DQUICKGELU, EPI_DQUICKGELU_D8, EPI_F32, EPI_QUI
                    EPI_RESIDUAL_F32, EPI_SCALE_F32,
                    call, query)
 
-BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+BF16, F32, F16, I64 = torch.bfloat16, torch.float32, torch.float16, torch.int64
 
 # order of the 12 per-layer parameters handed to BackboneFn (reference names, cvap/module/val.py:496-507)
 BLOCK_PARAM_NAMES = (
@@ -146,10 +146,10 @@ def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
 
 
 def layernorm_fwd(x: torch.Tensor, gamma, beta, *, want_bf16=True, want_f32=False, rows: Optional[int] = None,
-                  ldx: Optional[int] = None, add: Optional[torch.Tensor] = None, want_sum=False):
-    """x fp32 [M, D] (or `rows` rows with stride `ldx`) -> (y_bf16 | None, y_f32 | None, mean, rstd[, x + add]).
-    `add` (bf16 [M, D]) fuses the block's residual add in front of the norm; want_sum returns the new stream."""
-    _need(x, F32, "layernorm_fwd.x")
+                  ldx: Optional[int] = None, add: Optional[torch.Tensor] = None, want_sum=False, sum_f16=False):
+    """x fp32 | fp16 [M, D] (or `rows` rows with stride `ldx`) -> (y_bf16 | None, y_f32 | None, mean, rstd[, x + add]).
+    `add` (bf16 [M, D]) fuses the block's residual add in front of the norm; want_sum returns the new stream (fp16 with sum_f16)."""
+    _need(x, x.dtype if x.dtype == F16 else F32, "layernorm_fwd.x")
     D = x.shape[-1]
     M = rows if rows is not None else x.shape[0]
     ldx = ldx if ldx is not None else x.stride(0)
@@ -157,17 +157,20 @@ def layernorm_fwd(x: torch.Tensor, gamma, beta, *, want_bf16=True, want_f32=Fals
     y32 = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
     mean = torch.empty((M,), dtype=F32, device=x.device)
     rstd = torch.empty((M,), dtype=F32, device=x.device)
-    xsum = torch.empty((M, D), dtype=F32, device=x.device) if (add is not None and want_sum) else None
-    call("vipant_layernorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32),
-         mean.data_ptr(), rstd.data_ptr(), M, D, _ptr(add), _ptr(xsum), _stream())
+    xsum = torch.empty((M, D), dtype=F16 if sum_f16 else F32, device=x.device) if (add is not None and want_sum) else None
+    flags = (_ffi.STREAM_IN_F16 if x.dtype == F16 else 0) | (_ffi.STREAM_OUT_F16 if sum_f16 else 0)
+    call("vipant_layernorm_fwd_e4m3", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32),
+         mean.data_ptr(), rstd.data_ptr(), M, D, _ptr(add), _ptr(xsum), None, None, flags, _stream())
     if add is not None:
         return y, y32, mean, rstd, xsum
     return y, y32, mean, rstd
 
 
 def residual_add(x: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
-    out = torch.empty_like(x)
-    call("vipant_residual_add", x.data_ptr(), add.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    """fp32 out = x (fp32 or fp16 stream) + add (bf16)."""
+    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    call("vipant_residual_add", x.data_ptr(), add.data_ptr(), out.data_ptr(), x.numel(),
+         _ffi.STREAM_IN_F16 if x.dtype == F16 else 0, _stream())
     return out
 
 
@@ -178,7 +181,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=
     ldx = ldx if ldx is not None else x.stride(0)
     lddx = lddx if lddx is not None else (dx.stride(0) if dx is not None else D)
     ws = scratch("ln_bwd", query("vipant_layernorm_bwd_workspace_bytes", M, D), x.device)
-    call("vipant_layernorm_bwd", dy.data_ptr(), int(dy.dtype == F32), x.data_ptr(), ldx, mean.data_ptr(),
+    call("vipant_layernorm_bwd", dy.data_ptr(), int(dy.dtype == F32) | (_ffi.LN_X_F16 if x.dtype == F16 else 0), x.data_ptr(), ldx, mean.data_ptr(),
          rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), _ptr(dx), lddx, _ptr(dx_bf16), dgamma.data_ptr(),
          dbeta.data_ptr(), _ptr(dx_colsum), int(accumulate), M, D, ws.data_ptr(), ws.numel(), _stream())
 
@@ -390,7 +393,7 @@ class BackboneFn(torch.autograd.Function):
     vipant_gemm_bias_residual_*, vipant_ln_mlp_quickgelu_*."""
 
     @staticmethod
-    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, *params):
+    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, stream_f16, *params):
         _need(x, F32, "backbone.x")
         M, D = x.shape
         assert M == batch * S and len(params) % 12 == 0
@@ -404,6 +407,15 @@ class BackboneFn(torch.autograd.Function):
 
         def new(cols, dtype=BF16):
             return torch.empty((M, cols), dtype=dtype, device=dev)
+        # `running.stream_dtype: fp16`: inside the stack the residual stream is kept in the reference's own autocast precision
+        # (clip/model.py:157-160) -- every LayerNorm pass reads and writes 2 instead of 4 bytes per element of it, and so do the
+        # saved copies the backward reads; statistics stay fp32, the norm is taken on the unrounded sum, and the tensors that
+        # cross the autograd boundary (the stack's input and output) stay fp32
+        SDT = F16 if stream_f16 else F32
+        out16 = _ffi.STREAM_OUT_F16 if stream_f16 else 0
+
+        def sflags(t):
+            return (_ffi.STREAM_IN_F16 if t.dtype == F16 else 0) | out16
         # Per block (cvap/module/val.py:519-522):  x1 = x + attn(ln_1(x));  x2 = x1 + mlp(ln_2(x1)).
         # The branch outputs y1, y2 leave their contraction as bf16 and the residual add is fused into the NEXT
         # LayerNorm pass (fp32 stream in, fp32 stream + bf16 normalised activations out), so every contraction has a
@@ -442,27 +454,27 @@ class BackboneFn(torch.autograd.Function):
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
             # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
-            xs = new(D, F32) if y_prev is not None else None
+            xs = new(D, SDT) if y_prev is not None else None
             call("vipant_ln_qkv_fwd_e4m3", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
                  bqkv.data_ptr(), h1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D,
-                 C.byref(fp8_plan(q_qkv, None, act)) if fp8 else None, st)
+                 C.byref(fp8_plan(q_qkv, None, act)) if fp8 else None, sflags(x), st)
             if xs is not None:
                 x = xs
             o, lse = mha_fwd(qkv, batch, S, H, causal)
             call("vipant_gemm_bias_residual_fwd_e4m3", o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(), M, D, D,
                  C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
             # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
-            x1 = new(D, F32)
+            x1 = new(D, SDT)
             if "gemm_nt" in KERNEL_PROBE:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
-                call("vipant_layernorm_fwd", x.data_ptr(), D, ln2w.data_ptr(), ln2b.data_ptr(), h2.data_ptr(), None,
-                     mean2.data_ptr(), rstd2.data_ptr(), M, D, y1.data_ptr(), x1.data_ptr(), st)
+                call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, ln2w.data_ptr(), ln2b.data_ptr(), h2.data_ptr(), None,
+                     mean2.data_ptr(), rstd2.data_ptr(), M, D, y1.data_ptr(), x1.data_ptr(), None, None, sflags(x), st)
                 gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU_D8)
                 gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             else:
                 call("vipant_ln_mlp_quickgelu_fwd_e4m3", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
                      wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
                      rstd2.data_ptr(), u.data_ptr(), g.data_ptr(), y2.data_ptr(), M, D,
-                     C.byref(fp8_plan(q_fc, q_pr, act)) if fp8 else None, st)
+                     C.byref(fp8_plan(q_fc, q_pr, act)) if fp8 else None, sflags(x), st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
@@ -526,7 +538,7 @@ class BackboneFn(torch.autograd.Function):
                  h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq)) if fp8 else None, st)
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
@@ -536,7 +548,7 @@ class BackboneFn(torch.autograd.Function):
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None, st)
+                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None, _ffi.STREAM_IN_F16 if x.dtype == F16 else 0, st)
             del dqkv
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
@@ -548,8 +560,8 @@ class BackboneFn(torch.autograd.Function):
         if dx is None and need[0]:
             dx = torch.empty((M, D), dtype=F32, device=dev)
             call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
-        out_grads = [gr if need[7 + i] else None for i, gr in enumerate(grads)]
-        return (dx if need[0] else None, None, None, None, None, None, None, *out_grads)
+        out_grads = [gr if need[8 + i] else None for i, gr in enumerate(grads)]
+        return (dx if need[0] else None, None, None, None, None, None, None, None, *out_grads)
 
 
 # ---------------------------------------------------------------------------------- read-out
