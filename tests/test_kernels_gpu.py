@@ -378,6 +378,7 @@ def test_infonce_golden(ops, golden, B, tag):
 
 
 @pytest.mark.parametrize("B,row0,nrows", [(512, 0, 512), (1000, 0, 1000), (1024, 256, 256), (4096, 3584, 512),
+                                          (8192, 7168, 1024),                      # BASELINE.json configs[4]: 8 x 1024 clips
                                           (432, 108, 108), (432, 324, 108), (8, 4, 4), (30, 3, 5)])      # strips off the 8-row grid
 def test_infonce_large_and_sliced(ops, B, row0, nrows):
     from oracle import ref_cpu as R
