@@ -264,7 +264,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     # one rank per GPU; with fewer visible GPUs than ranks (the 2-rank test on a 1-GPU box) ranks share devices round-robin
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    local_rank, ndev = int(os.environ.get("LOCAL_RANK", "0")), max(torch.cuda.device_count(), 1)
+    if os.environ.get("VIPANT_DIST_BACKEND", "nccl") == "nccl" and local_rank >= ndev:
+        raise RuntimeError(f"LOCAL_RANK {local_rank} but only {ndev} visible GPU(s): RCCL takes one GPU per rank")
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)      # launched by torch.distributed.run

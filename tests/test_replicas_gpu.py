@@ -95,7 +95,7 @@ def test_two_replicas_match_single_process_with_e4m3_contractions(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_two_replicas_with_micro_batches_match_single_process(tmp_path):
-    """`running.micro_batch` under replicas (every micro-batch's backward hands its own gradient buckets to the reduction; a
+    """`running.micro_batch` under replicas (the micro-batches accumulate locally, the accumulated gradients are reduced ONCE; a
     parameter's reduced slices are summed): two replicas running two micro-batches each equal one process on the whole batch."""
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     mp.spawn(_run, args=(1, 0, one), nprocs=1, join=True)

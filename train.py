@@ -36,9 +36,12 @@ def main(cfg, rank, device, manager):
 def train(argv=None):
     cfg = compose(sys.argv[1:] if argv is None else argv)
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 or cfg.mode == "ddp" and "RANK" in os.environ:
-        local_rank = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
         backend = os.environ.get("VIPANT_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for shared-GPU tests
+        local_rank, ndev = int(os.environ.get("LOCAL_RANK", 0)), max(torch.cuda.device_count(), 1)
+        if backend == "nccl" and local_rank >= ndev:                # RCCL needs one GPU per rank: fail here, not inside its init
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {ndev} visible GPU(s): RCCL takes one GPU per rank")
+        local_rank %= ndev                                          # shared-GPU gloo tests: ranks wrap around the devices
+        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:

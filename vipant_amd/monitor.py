@@ -89,6 +89,9 @@ class Monitor(object):
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):
                     head.encoder.recompute_mlp = True
+        if cfg.running.get("grad_stream", None) is not None:        # bf16 (default) | fp32 master of the stream gradient
+            from . import ops
+            ops.GRAD_STREAM_F32 = str(cfg.running.grad_stream).lower() in ("fp32", "float32")
         # the residual stream inside every transformer stack: fp16 (the reference's autocast precision; default) or fp32;
         # LayerNorm statistics are fp32 either way
         stream_f16 = str(cfg.running.get("stream_dtype", "fp16")).lower() in ("fp16", "float16", "half")
@@ -170,9 +173,25 @@ class Monitor(object):
             feats[m].requires_grad_()
         loss = self.model.loss_from_features(*feats)
         loss.backward()
-        for a, b in cuts:
-            again = self.model.features(images[a:b], audios[a:b], text[a:b] if text is not None else None)
-            torch.autograd.backward([again[m] for m in live], [feats[m].grad[a:b] for m in live])
+        if not live:                       # every tower frozen: only the loss head trains, nothing to re-run
+            return loss
+        # Pass 3 under data-parallel replicas: the per-block reduction buckets of the stacks are switched off for the micro-batches
+        # -- each one would start a full set of all-reduces (n_micro x the traffic and n_micro flat gradient copies) -- autograd
+        # accumulates locally instead and `step()` reduces the accumulated gradients ONCE (all parameters through reduce_params).
+        # Towers that are frozen keep their pass-1 features: only the live modalities are run again.
+        stacks = [h.encoder for h in heads if h is not None and hasattr(h, "encoder")]
+        saved_sync = [st.grad_sync for st in stacks]
+        for st in stacks:
+            st.grad_sync = None
+        try:
+            for a, b in cuts:
+                again = self.model.features(images[a:b] if 0 in live else None, audios[a:b] if 1 in live else None,
+                                            text[a:b] if (2 in live and text is not None) else None)
+                torch.autograd.backward([again[m] for m in live], [feats[m].grad[a:b] for m in live])
+        finally:
+            for st, gs in zip(stacks, saved_sync):
+                st.grad_sync = gs
+        self._micro_step = True
         return loss
 
     def step(self, images, audios, text):
@@ -185,7 +204,9 @@ class Monitor(object):
             loss = self.model(images, audios, text if self.with_text else None)
             loss.backward()
         if self.grad_sync is not None:
-            rest = [p for p in self.params if not getattr(p, "_vipant_bucketed", False)]
+            micro = getattr(self, "_micro_step", False)         # micro-batched step: nothing went through a per-block bucket
+            self._micro_step = False
+            rest = [p for p in self.params if micro or not getattr(p, "_vipant_bucketed", False)]
             if self.model.loss_head is not None and self.cfg.running.get("negatives", "global") == "global":
                 skip = {id(p) for p in self.model.loss_head.parameters()}      # complete on every rank already
                 rest = [p for p in rest if id(p) not in skip]
@@ -295,6 +316,11 @@ class Monitor(object):
         if ocfg.use_lars:
             self.optimizer = LARS(param_groups, lr=0., weight_decay=ocfg.weight_decay,
                                   weight_decay_filter=exclude_bias_or_norm, lars_adaptation_filter=exclude_bias_or_norm)
+            # `running.batch_size` is PER PROCESS here (one process per GPU), while the reference's dp mode feeds every GPU from
+            # one process: say which global batch and base learning rate this launch trains with (module/lars.py)
+            world = parallel.world_size()
+            self.echo(f"LARS schedule: per-process batch {ocfg.batch_size} x {world} replica(s) = global batch "
+                      f"{ocfg.batch_size * world}, base lr {ocfg.batch_size * world / 256:g}")
         else:
             # cvalp.py:338-342: any torch.optim optimizer + lr scheduler named in the config (`optimizer.optimizer`,
             # `optimizer.scheduler`).  The update itself runs through torch's own optimizer kernels -- only LARS, the default

@@ -302,6 +302,9 @@ def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
     key = (w.data_ptr(), w._version, tuple(w.shape), transpose_only)
     hit = _frozen_cache.get(key)
     if hit is None:
+        # an updated weight (the optimizer bumps its version): drop the copies made from its earlier values
+        for stale in [k for k in _frozen_cache if k[0] == key[0] and k[2:] == key[2:] and k[1] != key[1]]:
+            _frozen_cache.pop(stale)
         while len(_frozen_cache) >= 1024:
             _frozen_cache.pop(next(iter(_frozen_cache)))
         hit = (cast_bf16(w.detach(), transpose=transpose_only), w.untyped_storage())
@@ -382,7 +385,8 @@ class _LayerGrads:
             off += p
 
 
-_GRAD_STREAM_F32 = os.environ.get("VIPANT_GRAD_STREAM", "bf16") == "fp32"
+# precision of the residual-stream GRADIENT: `running.grad_stream` (bf16 | fp32; monitor.py sets it), default from the environment
+GRAD_STREAM_F32 = os.environ.get("VIPANT_GRAD_STREAM", "bf16") == "fp32"
 
 
 class BackboneFn(torch.autograd.Function):
@@ -501,7 +505,7 @@ class BackboneFn(torch.autograd.Function):
         # backward 10 instead of 16 B per element); the forward stream stays fp32, so the loss and the features are untouched and
         # the gradients move from ~1.3 % to ~1.6 % rel-L2 of the fp32 reference (profiles/r2_stream_precision.md, model D; the
         # reference's own GPU path keeps this stream in fp16).  VIPANT_GRAD_STREAM=fp32: fp32 master + bf16 copy, both in place.
-        if _GRAD_STREAM_F32:
+        if GRAD_STREAM_F32:
             dx = dx_in.contiguous().clone()
             dx_b = cast_bf16_flat(dx)
         else:
