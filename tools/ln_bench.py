@@ -21,3 +21,10 @@ def bwd_bf16():
     ops.call("vipant_layernorm_bwd", dy.data_ptr(), 2, x.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dxb.data_ptr(), None, D,
              dxb.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(), st)
 print("ln_bwd bf16 stream:", round(t(bwd_bf16), 1), "us  (1.24 GB)")
+x16 = x.to(torch.float16)
+_, _, mean16, rstd16 = ops.layernorm_fwd(x16, g, b)
+def bwd_f16():
+    ops.call("vipant_layernorm_bwd", dy.data_ptr(), 2 | 4, x16.data_ptr(), D, mean16.data_ptr(), rstd16.data_ptr(), g.data_ptr(), dxb.data_ptr(), None, D,
+             dxb.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(), st)
+print("ln_bwd bf16 gradient stream, fp16 rows:", round(t(bwd_f16), 1), "us  (0.99 GB)")
+print("ln_fwd + add, fp16 stream:", round(t(lambda: ops.layernorm_fwd(x16,g,b,add=y,want_sum=True,sum_f16=True)),1), "us  (0.99 GB)")

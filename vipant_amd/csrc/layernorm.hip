@@ -1,6 +1,9 @@
 // LayerNorm forward / backward with fp32 statistics (clip/model.py:154-160, eps = 1e-5).
 // HBM-bound: one wave per token row, 16-byte accesses, wave-shuffle reductions, fp32 in / bf16 out so
 // that the normalised activations feed the next MFMA contraction without another cast pass.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
 // Per-block partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to `partial` [grid, 2, D].
 // DRES_BF16: the residual-stream gradient is a bf16 [M, D] tensor (read here, may be the same buffer as dxb: a lane reads its
 // elements of a row before it writes them) instead of an fp32 one.
-template <int NV, bool DY_F32, bool DRES_BF16, typename XT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const XT* __restrict__ x,
+template <int NV, bool DY_F32, bool DRES_BF16, typename XT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const void* __restrict__ dy_, const XT* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const void* dres_, float* dx, int64_t lddx,
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const bf16_t* dresb = DRES_BF16 ? (const bf16_t*)dres_ : nullptr;
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)blockIdx.x * NWV + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * NWV;
     f32x4 gv[NV], dg[NV], db[NV], dsum[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
@@ -132,21 +135,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         db[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         dsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int64_t row = wave; row < M; row += nwaves) {
-        const float mu = mean[row], rs = rstd[row];
+    // Two rows in flight per wave: row r + nwaves is requested before row r is reduced.  With 512 persistent workgroups (8 waves
+    // per CU) one row per wave left ~36 KB in flight per CU and the kernel ran at the latency, not at the bandwidth (4.75 TB/s).
+    using DyRaw = typename std::conditional<DY_F32, f32x4, bf16x4>::type;
+    using XRaw = typename std::conditional<sizeof(XT) == 4, f32x4, f16x4>::type;
+    struct Raw { DyRaw dy[NV]; XRaw x[NV]; bf16x4 rb[NV]; f32x4 rf[NV]; float mu, rs; };
+    auto load_row = [&](int64_t row, Raw& r) {
+        r.mu = mean[row]; r.rs = rstd[row];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int col = (t * 64 + lane) * 4;
+            r.dy[t] = *(const DyRaw*)((const typename std::conditional<DY_F32, float, bf16_t>::type*)dy_ + row * D + col);
+            r.x[t] = *(const XRaw*)(x + row * ldx + col);
+            if (DRES_BF16) r.rb[t] = *(const bf16x4*)(dresb + row * D + col);
+            else if (dres != nullptr) r.rf[t] = *(const f32x4*)(dres + row * lddx + col);
+        }
+    };
+    auto reduce_row = [&](int64_t row, const Raw& r) {
+        const float mu = r.mu, rs = r.rs;
         f32x4 xh[NV], g[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
-            const int col = (t * 64 + lane) * 4;
-            f32x4 dyv;
-            if (DY_F32) {
-                dyv = *(const f32x4*)((const float*)dy_ + row * D + col);
-            } else {
-                const bf16x4 b = *(const bf16x4*)((const bf16_t*)dy_ + row * D + col);
-                dyv = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-            }
-            xh[t] = (load_stream4(x + row * ldx + col) - mu) * rs;
+            f32x4 dyv, xv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dyv[e] = (float)r.dy[t][e]; xv[e] = (float)r.x[t][e]; }
+            xh[t] = (xv - mu) * rs;
             g[t] = dyv * gv[t];
             dg[t] += dyv * xh[t];
             db[t] += dyv;
@@ -159,30 +173,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int t = 0; t < NV; ++t) {
             const int col = (t * 64 + lane) * 4;
             f32x4 o = (g[t] - s1 - xh[t] * s2) * rs;
-            if (DRES_BF16) {
-                const bf16x4 rb = *(const bf16x4*)(dresb + row * D + col);
-                o += f32x4{(float)rb[0], (float)rb[1], (float)rb[2], (float)rb[3]};
-            } else if (dres != nullptr) {
-                o += *(const f32x4*)(dres + row * lddx + col);
-            }
+            if (DRES_BF16) o += f32x4{(float)r.rb[t][0], (float)r.rb[t][1], (float)r.rb[t][2], (float)r.rb[t][3]};
+            else if (dres != nullptr) o += r.rf[t];
             dsum[t] += o;
             if (dx != nullptr) *(f32x4*)(dx + row * lddx + col) = o;
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
             g[t] = o;
         }
         if (q8 != nullptr) quant_row_e4m3<NV>(g, q8 + row * D, q8s + row, lane);
+    };
+    // a ring of RING rows per wave: row r + (RING - 1) nwaves is requested before row r is reduced (static indices: the loop
+    // body is written out RING times)
+    constexpr int RING = 2;          // measured: 4 rows in flight per wave are not faster (191.7 vs 190.3 us)
+    Raw ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (wave + i * nwaves < M) load_row(wave + i * nwaves, ring[i]);
+    for (int64_t row = wave; row < M; row += RING * nwaves) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            const int64_t r = row + i * nwaves;
+            if (r + (RING - 1) * nwaves < M) load_row(r + (RING - 1) * nwaves, ring[(i + RING - 1) % RING]);
+            if (r < M) reduce_row(r, ring[i]);
+        }
     }
     // block reduction of the 4 waves' column sums, one quantity at a time through a [4][D] LDS buffer (12 KiB at
     // D = 768: does not limit residency), then one row of partials per BLOCK
-    __shared__ float red[4 * D];
+    __shared__ float red[NWV * D];
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
 #pragma unroll
         for (int t = 0; t < NV; ++t)
             *(f32x4*)(red + wv * D + (t * 64 + lane) * 4) = which == 0 ? dg[t] : (which == 1 ? db[t] : dsum[t]);
         __syncthreads();
-        for (int i = threadIdx.x; i < D; i += 256)
-            partial[((int64_t)blockIdx.x * 3 + which) * D + i] = red[i] + red[D + i] + red[2 * D + i] + red[3 * D + i];
+        for (int i = threadIdx.x; i < D; i += NWV * 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) acc += red[w * D + i];
+            partial[((int64_t)blockIdx.x * 3 + which) * D + i] = acc;
+        }
         __syncthreads();
     }
 }
@@ -209,11 +238,13 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
     }
 }
 
-// persistent workgroups (the column sums accumulate in registers across a wave's rows); 512-640 measured best at M = 161 792
-// (242 us; 288 us with 1024, 356 us with 256: fewer partial rows to write and reduce against memory-level parallelism)
+// persistent workgroups (the column sums accumulate in registers across a wave's rows), ONE per CU with two rows in flight per wave:
+// at M = 161 792 with fp16 rows 188-190 us for 256 workgroups; 226 / 220 / 222 / 201-205 us for 192 / 320 / 384 / 512; 8-wave
+// workgroups 200-206 us; the round-2 kernel (one row per wave, 512 workgroups) 226 us.  VIPANT_LN_BLOCKS overrides (timing only)
 int ln_blocks(int64_t M) {
-    int64_t b = ceil_div(M, 4);
-    return (int)(b > 512 ? 512 : b);
+    static const int cap = getenv("VIPANT_LN_BLOCKS") ? atoi(getenv("VIPANT_LN_BLOCKS")) : 256;      // timing experiments
+    int64_t b = ceil_div(M, 16);
+    return (int)(b > cap ? cap : b);
 }
 
 }  // namespace
@@ -281,8 +312,8 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
                    "layernorm_bwd: a bf16 residual gradient needs dres and a bf16 dy");
     const bool x16 = (flags & VIPANT_LN_X_F16) != 0;
 #define LN_BWD_T(NV, A, B, XT)                                                                                                 \
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, A, B, XT>), dim3(blocks), dim3(256), 0, s, dy, (const XT*)x, ldx, mean, rstd, gamma, dres, \
-                       dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale)
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, A, B, XT, 4>), dim3(blocks), dim3(256), 0, s, dy, (const XT*)x, ldx, mean, rstd, gamma, \
+                       dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale)
 #define LN_BWD(NV)                                                                                                   \
     do {                                                                                                             \
         if (dy_is_f32) { if (x16) LN_BWD_T(NV, true, false, f16_t); else LN_BWD_T(NV, true, false, float); }         \
