@@ -32,7 +32,7 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
     return layers * S * (24 * width * width + 4 * S * width) + 2 * P * kpatch * width + 2 * width * embed
 
 
-PMC_FILE = "profiles/r2_pmc_traffic.json"
+PMC_FILE = "profiles/r3_pmc_traffic.json"
 
 
 def pmc_traffic(M, N, K):
