@@ -164,6 +164,8 @@ int32_t vipant_embed_tokens(const int64_t* tokens, const float* table, const flo
 int32_t vipant_gather_rows(const float* x, const int64_t* idx, float* out, int64_t n, int64_t rows_per_item,
                            int64_t D, void* stream);
 /* scatter-add of the read-out gradient back into a zeroed token-major gradient (backward of gather_rows). */
+int32_t vipant_scatter_rows_bf16(const float* g, const int64_t* idx, uint16_t* dx_bf16, uint16_t* compact_bf16, int64_t n,
+                                 int64_t rows_per_item, int64_t D, void* stream);
 int32_t vipant_scatter_rows(const float* g, const int64_t* idx, float* dx, int64_t n, int64_t rows_per_item,
                             int64_t D, void* stream);
 
@@ -330,7 +332,8 @@ int32_t vipant_patch_embed_ln_fwd(const float* x, const float* conv_w, const flo
 size_t vipant_patch_embed_ln_bwd_workspace_bytes(int64_t b, int64_t P, int64_t Dw, int64_t kcols);
 /* dtokens fp32 [b*S,Dw], dpatches bf16 [b*P,Dw], dw_eff fp32 [Dw,kcols] scratch; dconv fp32 [Dw,Cw,khw] (mean_channels; else
  * dw_eff IS the weight gradient); dcls fp32 [Dw]; dpos fp32 [rows >= S, Dw] must arrive zeroed. */
-int32_t vipant_patch_embed_ln_bwd(const float* dout, const float* tokens, const float* mean, const float* rstd, const float* gamma,
+/* dout: gradient of the residual stream the stack hands back -- fp32 [b*S,Dw], or (dout_bf16 != 0) its bf16 stream gradient as is. */
+int32_t vipant_patch_embed_ln_bwd(const void* dout, int32_t dout_bf16, const float* tokens, const float* mean, const float* rstd, const float* gamma,
                                   const uint16_t* patches, float* dtokens, uint16_t* dpatches, float* dw_eff, float* dconv,
                                   float* dcls, float* dpos, float* dgamma, float* dbeta, int64_t b, int64_t P, int64_t Dw,
                                   int64_t Cw, int64_t khw, int32_t mean_channels, void* workspace, size_t workspace_bytes,
@@ -346,6 +349,9 @@ int32_t vipant_cls_ln_proj_l2norm_fwd(const float* x, const int64_t* idx, const 
 size_t vipant_cls_ln_proj_l2norm_bwd_workspace_bytes(int64_t batch, int64_t D, int64_t E);
 /* dout fp32 [batch,E]; proj bf16 [D,E]; dfeat bf16 [batch,E], dy bf16 [batch,D], drows fp32 [batch,D] scratch; dx fp32 [batch*S,D]
  * zeroed by the caller; dproj fp32 [D,E]. */
+/* dx (token-major, zeroed by the caller) receives the read-out rows' gradient; or, compact form: `drows` fp32 [batch, D] receives
+ * them (always for idx != NULL; for the cls read-out when drows != NULL) and dx may be NULL -- the transformer stack's backward
+ * scatters them into its bf16 stream gradient itself (vipant_scatter_rows_bf16) instead of reading a dense fp32 matrix of zeros. */
 int32_t vipant_cls_ln_proj_l2norm_bwd(const float* dout, const float* out, const float* norm, const float* x, const int64_t* idx,
                                       const float* rows, const uint16_t* y, const float* mean, const float* rstd,
                                       const float* gamma, const uint16_t* proj, uint16_t* dfeat, uint16_t* dy, float* drows,

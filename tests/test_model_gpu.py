@@ -252,6 +252,60 @@ def test_end_to_end_golden(M, golden, tag, L, b, T, Fq, stream):
     assert rel_l2(grads[f"encoder.resblocks.{L - 1}.mlp.c_fc.bias"], g["g_last_fc_bias"]) < 5e-2
 
 
+def _audio_step(M, handoff, monkeypatch, extra_consumer=False):
+    from vipant_amd import ops
+    monkeypatch.setattr(ops, "NODE_HANDOFF", handoff)
+    L, b, T, Fq = 2, 8, 256, 64
+    head = M.build_audio_head(audio_cfg(T, Fq, L))
+    S = head.misc.positional_embedding.shape[0]
+    head.load_state_dict(gen.det_weights("e2e/L2", gen.vit_head_shapes(768, L, 512, S)), strict=True)
+    lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
+    head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
+    aud = gen.det_randn("e2e/L2/aud", (b, 1, T, Fq)).to(DEV)
+    img = ops.l2_normalize(gen.det_randn("e2e/L2/img", (b, 512)).to(DEV))
+    seen = {}
+    if extra_consumer:       # a second consumer of the stack's output and of its input: autograd sums real gradients into both
+        pre = head.pre_encoder(aud, positional_embedding=head.misc.pos_embedding, class_embedding=head.misc.cls_embedding)
+        x = head.encoder(pre)
+        feat = head.post_encoder(x)
+        feat = feat / feat.norm(dim=-1, keepdim=True)
+        loss = lhead(img, feat, None, normalized=True) + 1e-3 * x.float().square().mean() + 1e-3 * pre.float().square().mean()
+    else:
+        feat = head(aud, normalized=True)
+        loss = lhead(img, feat, None, normalized=True)
+        node = feat.grad_fn
+        while node is not None and getattr(node, "_vipant_kind", None) != "stack":
+            node = node.next_functions[0][0] if node.next_functions else None
+        seen["stack"] = node
+    loss.backward()
+    return float(loss), {k: p.grad.clone() for k, p in head.named_parameters()}, seen
+
+
+def test_node_handoff_matches_dense_gradients(M, monkeypatch):
+    """The compact read-out gradient / bf16 stream gradient hand-off between the tower's three autograd nodes (vipant_amd/ops.py,
+    `_producer`) against dense fp32 gradients through autograd: same values; only the top block's c_proj.bias (column sums taken
+    over the compact rows instead of the dense matrix) may differ in summation order."""
+    l0, g0, _ = _audio_step(M, False, monkeypatch)
+    l1, g1, seen = _audio_step(M, True, monkeypatch)
+    assert seen["stack"] is not None and seen["stack"].patch_node is None and seen["stack"].readout_grad is None   # consumed
+    assert l0 == l1
+    for k in g0:
+        if k.endswith("resblocks.1.mlp.c_proj.bias"):
+            assert rel_l2(g1[k], g0[k]) < 1e-6, k
+        else:
+            assert torch.equal(g1[k], g0[k]), (k, rel_l2(g1[k], g0[k]))
+
+
+def test_node_handoff_with_other_consumers(M, monkeypatch):
+    """When something else also consumes the stack's input or output, autograd delivers a real gradient and the hand-off is
+    added to it: same gradients as with the hand-off switched off."""
+    l0, g0, _ = _audio_step(M, False, monkeypatch, extra_consumer=True)
+    l1, g1, _ = _audio_step(M, True, monkeypatch, extra_consumer=True)
+    assert abs(l0 - l1) < 1e-6
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) < 2e-3, (k, rel_l2(g1[k], g0[k]))     # bf16 rounding of (a + b) vs a, b separately
+
+
 @pytest.mark.parametrize("tag,L,b,T,Fq", [("L12", 12, 32, 256, 64), ("cfg2", 12, 64, 1024, 128)])
 def test_end_to_end_golden_e4m3(M, golden, tag, L, b, T, Fq):
     """`running.fp8_gemm` (BASELINE.json configs[4]) against the REFERENCE's own outputs, not against the bf16 HIP run: the same

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "vipant_embed_tokens": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_gather_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_scatter_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_scatter_rows_bf16": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_infonce_workspace_bytes": (_sz, [_i64, _i64]),
     "vipant_infonce_fwd_bwd": (_i32, [_p, _p, _p, _f32, _p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_retrieval_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
@@ -86,7 +87,7 @@ PROTOTYPES = {
     "vipant_ln_mlp_quickgelu_bwd": (_i32, [_p] * 20 + [_i64, _i64, _p, _sz, _p]),
     "vipant_patch_embed_ln_fwd": (_i32, [_p] * 13 + [_i64] * 10 + [_i32, _p]),
     "vipant_patch_embed_ln_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "vipant_patch_embed_ln_bwd": (_i32, [_p] * 14 + [_i64] * 5 + [_i32, _p, _sz, _p]),
+    "vipant_patch_embed_ln_bwd": (_i32, [_p, _i32] + [_p] * 13 + [_i64] * 5 + [_i32, _p, _sz, _p]),
     "vipant_cls_ln_proj_l2norm_fwd": (_i32, [_p] * 12 + [_i64] * 4 + [_i32, _p]),
     "vipant_cls_ln_proj_l2norm_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vipant_cls_ln_proj_l2norm_bwd": (_i32, [_p] * 18 + [_i64] * 4 + [_i32, _p, _sz, _p]),

@@ -238,7 +238,7 @@ extern "C" size_t vipant_patch_embed_ln_bwd_workspace_bytes(int64_t b, int64_t P
     return max_sz(vipant_gemm_tn_workspace_bytes(b * P, Dw, kcols), vipant_layernorm_bwd_workspace_bytes(b * (P + 1), Dw));
 }
 
-extern "C" int32_t vipant_patch_embed_ln_bwd(const float* dout, const float* tokens, const float* mean, const float* rstd,
+extern "C" int32_t vipant_patch_embed_ln_bwd(const void* dout, int32_t dout_bf16, const float* tokens, const float* mean, const float* rstd,
                                              const float* gamma, const uint16_t* patches, float* dtokens, uint16_t* dpatches,
                                              float* dw_eff, float* dconv, float* dcls, float* dpos, float* dgamma,
                                              float* dbeta, int64_t b, int64_t P, int64_t Dw, int64_t Cw, int64_t khw,
@@ -246,8 +246,8 @@ extern "C" int32_t vipant_patch_embed_ln_bwd(const float* dout, const float* tok
     const int64_t kcols = (mean_channels ? 1 : Cw) * khw;
     VIPANT_REQUIRE(workspace_bytes >= vipant_patch_embed_ln_bwd_workspace_bytes(b, P, Dw, kcols), VIPANT_ENOWORKSPACE,
                    "patch_embed_ln_bwd: workspace too small");
-    TRY(vipant_layernorm_bwd(dout, 1, tokens, Dw, mean, rstd, gamma, nullptr, dtokens, Dw, nullptr, dgamma, dbeta, nullptr, 0,
-                             b * (P + 1), Dw, workspace, workspace_bytes, stream));
+    TRY(vipant_layernorm_bwd(dout, dout_bf16 ? 0 : VIPANT_LN_DY_F32, tokens, Dw, mean, rstd, gamma, nullptr, dtokens, Dw, nullptr, dgamma,
+                             dbeta, nullptr, 0, b * (P + 1), Dw, workspace, workspace_bytes, stream));
     TRY(vipant_assemble_tokens_bwd(dtokens, dpatches, dcls, dpos, 0, b, P, Dw, stream));    // dpos must arrive zeroed
     TRY(vipant_gemm_tn(dpatches, Dw, patches, kcols, dw_eff, kcols, b * P, Dw, kcols, 0, nullptr, workspace, workspace_bytes,
                        stream));
@@ -300,11 +300,18 @@ extern "C" int32_t vipant_cls_ln_proj_l2norm_bwd(const float* dout, const float*
     else TRY(vipant_cast_bf16(dout, dfeat, nullptr, 1, batch * E, stream));
     TRY(vipant_gemm_nt(dfeat, E, proj, E, dy, D, nullptr, nullptr, 1.0f, batch, D, E, VIPANT_EPI_BF16, stream));   // dy = dfeat . proj^T
     TRY(vipant_gemm_tn(y, D, dfeat, E, dproj, E, batch, D, E, 0, nullptr, workspace, workspace_bytes, stream));
-    if (idx == nullptr)
+    if (idx == nullptr) {
+        // cls rows: in place in the token-major dx (row stride S * D), or -- `drows` given -- as compact rows [batch, D]: the caller
+        // then scatters them itself (the stack's backward wants them as bf16 rows of its stream gradient, not as a dense fp32 matrix)
+        if (drows != nullptr)
+            return vipant_layernorm_bwd(dy, 0, x, S * D, mean, rstd, gamma, nullptr, drows, D, nullptr, dgamma, dbeta, nullptr, 0,
+                                        batch, D, workspace, workspace_bytes, stream);
         return vipant_layernorm_bwd(dy, 0, x, S * D, mean, rstd, gamma, nullptr, dx, S * D, nullptr, dgamma, dbeta, nullptr, 0,
                                     batch, D, workspace, workspace_bytes, stream);
+    }
     TRY(vipant_layernorm_bwd(dy, 0, rows, D, mean, rstd, gamma, nullptr, drows, D, nullptr, dgamma, dbeta, nullptr, 0, batch, D,
                              workspace, workspace_bytes, stream));
+    if (dx == nullptr) return VIPANT_OK;                  // compact form: the caller scatters drows
     return vipant_scatter_rows(drows, idx, dx, batch, S, D, stream);
 }
 

@@ -308,6 +308,21 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     }
 }
 
+// compact fp32 rows g [n, D] -> bf16 rows r_i = i * rpi + idx[i] (idx == NULL: + 0) of a ZEROED bf16 matrix, and their bf16 copy
+__global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                                                bf16_t* __restrict__ dx, bf16_t* __restrict__ compact, int64_t n,
+                                                                int64_t rpi, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        for (int c = lane * 4; c < D; c += 256) {
+            const bf16x4 v = f32x4_to_bf16x4(*(const f32x4*)(g + i * D + c));
+            *(bf16x4*)(dx + r * D + c) = v;
+            if (compact != nullptr) *(bf16x4*)(compact + i * D + c) = v;
+        }
+    }
+}
+
 // ---- column sums over tokens: thread = 8 columns, block = 512 columns x 4 row lanes, grid.y row chunks --
 constexpr int CS_ROWCHUNKS = 128;
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int64_t ldx, float* __restrict__ partial,
@@ -556,6 +571,15 @@ extern "C" int32_t vipant_scatter_rows(const float* g, const int64_t* idx, float
     VIPANT_REQUIRE(n > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "scatter_rows: bad shape");
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, g, idx, dx, n,
                        rows_per_item, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_scatter_rows_bf16(const float* g, const int64_t* idx, uint16_t* dx_bf16, uint16_t* compact_bf16, int64_t n,
+                                            int64_t rows_per_item, int64_t D, void* stream) {
+    VIPANT_REQUIRE(n > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "scatter_rows_bf16: bad shape");
+    hipLaunchKernelGGL(scatter_rows_bf16_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, g, idx, (bf16_t*)dx_bf16,
+                       (bf16_t*)compact_bf16, n, rows_per_item, (int)D);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

@@ -312,6 +312,44 @@ def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
     return hit[0][1] if transpose_only else hit[0][0]
 
 
+# ---------------------------------------------------------------------------------- node-to-node gradient hand-off
+# The three autograd nodes of a tower (patch embedding -> transformer stack -> read-out) exchange the residual stream as fp32
+# tensors, and autograd wants each node's input gradient as a dense fp32 tensor of that shape: for the read-out that is a
+# [M, D] matrix of zeros with `batch` non-zero rows (a 497 MB fill + a cast back to bf16 at cfg2), for the stack a bf16 -> fp32
+# cast that the patch embedding's LayerNorm backward immediately undoes.  When a node finds its neighbour in the autograd graph,
+# it hands the compact form over directly (an attribute on the neighbour's ctx) and returns a zero-stride placeholder of the
+# right shape; the receiver uses the hand-off only if what autograd delivers IS that placeholder (another consumer of the same
+# tensor makes autograd sum real gradients into it, and the dense path takes over, with the hand-off added in).
+_VIEW_NODES = ("ViewBackward0", "ReshapeAliasBackward0", "UnsafeViewBackward0", "AliasBackward0", "ViewBackward1")
+
+
+NODE_HANDOFF = os.environ.get("VIPANT_NODE_HANDOFF", "1") != "0"     # 0: dense fp32 gradients between the nodes (tests, A/B)
+
+
+def _producer(t: torch.Tensor, kind: str):
+    """The custom node of `kind` that produced `t` (looking through view / reshape nodes), or None."""
+    if not NODE_HANDOFF:
+        return None
+    node = t.grad_fn
+    for _ in range(4):
+        if node is None:
+            return None
+        if getattr(node, "_vipant_kind", None) == kind:
+            return node
+        if type(node).__name__ not in _VIEW_NODES or not node.next_functions:
+            return None
+        node = node.next_functions[0][0]
+    return None
+
+
+def _placeholder(shape, device) -> torch.Tensor:
+    return torch.zeros((), dtype=F32, device=device).expand(*shape)
+
+
+def _is_placeholder(t: torch.Tensor) -> bool:
+    return t.dim() == 2 and t.stride() == (0, 0)
+
+
 # ---------------------------------------------------------------------------------- patch embedding
 class PatchEmbedFn(torch.autograd.Function):
     """ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + MFMA contraction, cls token,
@@ -345,6 +383,8 @@ class PatchEmbedFn(torch.autograd.Function):
              mean.data_ptr(), rstd.data_ptr(), b, Cx, T, Fq, D, Cw, ph, pw, sh, sw, int(mean_ch), _stream())
         ctx.save_for_backward(patches, tok, mean, rstd, ln_w)
         ctx.meta = (b, P, D, Cw, ph * pw, mean_ch, tuple(conv_w.shape), tuple(pos.shape))
+        ctx._vipant_kind = "patch"
+        ctx.stream_grad = None          # the stack's bf16 stream gradient, handed over by BackboneFn.backward
         return out
 
     @staticmethod
@@ -352,7 +392,14 @@ class PatchEmbedFn(torch.autograd.Function):
         patches, tok, mean, rstd, ln_w = ctx.saved_tensors
         b, P, D, Cw, khw, mean_ch, conv_shape, pos_shape = ctx.meta
         dev = dout.device
-        dout = dout.contiguous()
+        handed, ctx.stream_grad = ctx.stream_grad, None
+        dout_bf16 = handed is not None and _is_placeholder(dout)
+        if dout_bf16:
+            dout = handed
+        else:
+            dout = dout.contiguous()
+            if handed is not None:      # another consumer of the stream contributed a real gradient: add the stack's to it
+                dout = dout + handed.to(F32)
         kcols = patches.shape[1]
         dtok = torch.empty_like(tok)
         dpatch = torch.empty((b * P, D), dtype=BF16, device=dev)
@@ -363,7 +410,7 @@ class PatchEmbedFn(torch.autograd.Function):
         dlnw = torch.empty((D,), dtype=F32, device=dev)
         dlnb = torch.empty((D,), dtype=F32, device=dev)
         ws = scratch("patch_embed_bwd", query("vipant_patch_embed_ln_bwd_workspace_bytes", b, P, D, kcols), dev)
-        call("vipant_patch_embed_ln_bwd", dout.data_ptr(), tok.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        call("vipant_patch_embed_ln_bwd", dout.data_ptr(), int(dout_bf16), tok.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
              ln_w.detach().data_ptr(), patches.data_ptr(), dtok.data_ptr(), dpatch.data_ptr(), dw_eff.data_ptr(),
              dconv.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), b, P, D, Cw, khw,
              int(mean_ch), ws.data_ptr(), ws.numel(), _stream())
@@ -399,6 +446,7 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, stream_f16, *params):
         _need(x, F32, "backbone.x")
+        x_in = x
         M, D = x.shape
         assert M == batch * S and len(params) % 12 == 0
         L, H = len(params) // 12, D // 64
@@ -490,6 +538,9 @@ class BackboneFn(torch.autograd.Function):
             ctx.wts = wts
             ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8)
             ctx.grad_sync = grad_sync
+            ctx._vipant_kind = "stack"
+            ctx.readout_grad = None                      # (idx | None, compact fp32 rows), handed over by ReadoutFn.backward
+            ctx.patch_node = _producer(x_in, "patch")    # the patch embedding that produced this stack's input, if any
         return x
 
     @staticmethod
@@ -505,12 +556,26 @@ class BackboneFn(torch.autograd.Function):
         # backward 10 instead of 16 B per element); the forward stream stays fp32, so the loss and the features are untouched and
         # the gradients move from ~1.3 % to ~1.6 % rel-L2 of the fp32 reference (profiles/r2_stream_precision.md, model D; the
         # reference's own GPU path keeps this stream in fp16).  VIPANT_GRAD_STREAM=fp32: fp32 master + bf16 copy, both in place.
-        if GRAD_STREAM_F32:
-            dx = dx_in.contiguous().clone()
-            dx_b = cast_bf16_flat(dx)
-        else:
+        handed, ctx.readout_grad = ctx.readout_grad, None
+        top_rows = None
+        if handed is not None and _is_placeholder(dx_in) and not GRAD_STREAM_F32:
+            # the read-out's gradient as compact rows: they go straight into a zeroed bf16 stream gradient
+            ridx, rows = handed
             dx = None
-            dx_b = cast_bf16_flat(dx_in.contiguous())
+            dx_b = torch.zeros((M, D), dtype=BF16, device=dev)
+            top_rows = torch.empty((rows.shape[0], D), dtype=BF16, device=dev)
+            call("vipant_scatter_rows_bf16", rows.data_ptr(), _ptr(ridx), dx_b.data_ptr(), top_rows.data_ptr(), rows.shape[0], S, D, st)
+        else:
+            if handed is not None:                       # dense gradient from another consumer: add the read-out rows to it
+                ridx, rows = handed
+                dx_in = dx_in.contiguous().clone()
+                call("vipant_scatter_rows", rows.data_ptr(), _ptr(ridx), dx_in.data_ptr(), rows.shape[0], S, D, st)
+            if GRAD_STREAM_F32:
+                dx = dx_in.contiguous().clone()
+                dx_b = cast_bf16_flat(dx)
+            else:
+                dx = None
+                dx_b = cast_bf16_flat(dx_in.contiguous())
         ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
         act = dyq = None
         if fp8:
@@ -524,7 +589,9 @@ class BackboneFn(torch.autograd.Function):
             g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
         grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
         lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
-        colsum(dx_b, lg.views[11])          # d c_proj.bias of the top block; lower blocks get theirs from ln_1's backward
+        # d c_proj.bias of the top block (lower blocks get theirs from ln_1's backward): column sums of the stream gradient, which
+        # with a handed-over read-out gradient has only those rows
+        colsum(top_rows if top_rows is not None else dx_b, lg.views[11])
         for l in reversed(range(L)):
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             ln1w, _, _, _, _, _, ln2w, _, _, bfc, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
@@ -561,9 +628,14 @@ class BackboneFn(torch.autograd.Function):
             lg = lg_below
         ctx.wts = None
         need = ctx.needs_input_grad
+        patch, ctx.patch_node = ctx.patch_node, None
         if dx is None and need[0]:
-            dx = torch.empty((M, D), dtype=F32, device=dev)
-            call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
+            if patch is not None:        # the patch embedding's LayerNorm backward takes the bf16 stream gradient as it is
+                patch.stream_grad = dx_b
+                dx = _placeholder((M, D), dev)
+            else:
+                dx = torch.empty((M, D), dtype=F32, device=dev)
+                call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
         out_grads = [gr if need[8 + i] else None for i, gr in enumerate(grads)]
         return (dx if need[0] else None, None, None, None, None, None, None, None, *out_grads)
 
@@ -576,6 +648,7 @@ class ReadoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, batch, S, ln_w, ln_b, proj, normalized):
         _need(x, F32, "readout.x")
+        x_arg = x
         x = x.contiguous()
         D, E = proj.shape
         dev = x.device
@@ -597,6 +670,7 @@ class ReadoutFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, idx, rows, y, mean, rstd, ln_w, proj_b, out, norm)
             ctx.meta = (batch, S, D, E, bool(normalized))
+            ctx.stack_node = _producer(x_arg, "stack")       # the transformer stack whose output is read out, if any
         return out
 
     @staticmethod
@@ -607,16 +681,21 @@ class ReadoutFn(torch.autograd.Function):
         dout = dout.contiguous()
         dfeat = torch.empty((batch, E), dtype=BF16, device=dev)
         dy = torch.empty((batch, D), dtype=BF16, device=dev)
-        drows = torch.empty((batch, D), dtype=F32, device=dev) if idx is not None else None
+        stack, ctx.stack_node = ctx.stack_node, None
+        compact = stack is not None and stack.readout_grad is None and ctx.needs_input_grad[0]
+        drows = torch.empty((batch, D), dtype=F32, device=dev) if (idx is not None or compact) else None
         dproj = torch.empty((D, E), dtype=F32, device=dev)
         dlnw = torch.empty((D,), dtype=F32, device=dev)
         dlnb = torch.empty((D,), dtype=F32, device=dev)
-        dx = torch.zeros_like(x)
+        dx = None if compact else torch.zeros_like(x)
         ws = scratch("readout_bwd", query("vipant_cls_ln_proj_l2norm_bwd_workspace_bytes", batch, D, E), dev)
         call("vipant_cls_ln_proj_l2norm_bwd", dout.data_ptr(), out.data_ptr(), _ptr(norm), x.data_ptr(), _ptr(idx), _ptr(rows),
              y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ln_w.detach().data_ptr(), proj_b.data_ptr(), dfeat.data_ptr(),
-             dy.data_ptr(), _ptr(drows), dx.data_ptr(), dproj.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), batch, S, D, E,
+             dy.data_ptr(), _ptr(drows), _ptr(dx), dproj.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), batch, S, D, E,
              int(normalized), ws.data_ptr(), ws.numel(), _stream())
+        if compact:                  # hand the rows to the stack's backward; autograd gets a zero-stride placeholder
+            stack.readout_grad = (idx, drows)
+            dx = _placeholder(tuple(x.shape), dev)
         return dx, None, None, None, dlnw, dlnb, dproj, None
 
 
