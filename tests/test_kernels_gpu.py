@@ -86,6 +86,28 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert_close(c32, 0.37 * (a.float() @ b.float().t()), 1e-4, 2e-3, "scale epilogue")
 
 
+@pytest.mark.parametrize("M,N,K", [(23117, 768, 1024),     # 91 x 3 tiles = 1 round + 17; 77 rows in the last panel
+                                   (70000, 768, 2304),     # 3 rounds + 54; last panel 112 rows
+                                   (8000, 2304, 768),      # 32 x 9 = 1 round + 32
+                                   (65536, 256, 1024)])    # exactly one round
+def test_gemm_nt_short_last_round(ops, M, N, K):
+    """The DEEP ping-pong schedule with a short last round of the persistent walk and a ragged last row panel: the reference
+    product, nothing written past the last row, and independence of where a row falls in the walk (written for the half-tile
+    split of the last round, profiles/r3_gemm_experiments.md; the split was not kept, the test is)."""
+    a, b = rnd(M, K, seed=31, dtype=torch.bfloat16), rnd(N, K, seed=32, dtype=torch.bfloat16, scale=0.05)
+    bias = rnd(N, seed=33)
+    c = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=DEV)        # one guard row behind the output
+    ops.gemm_nt(a, b, c[:M], bias=bias, epi=ops.EPI_BF16)
+    assert bool((c[M] == 7.0).all()), "wrote past the last row"
+    for lo in range(0, M, 16384):
+        hi = min(M, lo + 16384)
+        assert_close(c[lo:hi], a[lo:hi].float() @ b.float().t() + bias, 1e-2, 2e-2, f"rows {lo}..{hi}")
+    # a row-shifted problem changes which tile and round a row falls into: the shared rows must agree bit for bit
+    c2 = torch.empty(M - 256, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a[256:], b, c2, bias=bias, epi=ops.EPI_BF16)
+    assert torch.equal(c2, c[256:M])
+
+
 def test_gemm_nt_identity_layout(ops):
     """A = I with an asymmetric B catches a transposed / permuted C write."""
     K = 256
