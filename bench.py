@@ -27,9 +27,13 @@ D, L, E, HEADS = 768, 12, 512, 12
 DOMINANT_KERNEL = "gemm_nt_pp_kernel<6, 8, 2>"      # c_fc forward + QuickGELU, 8-bit QuickGELU' code (name as rocprofv3 prints it)
 
 
-def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E):
-    """L*S*(24 D^2 + 4 S D) + 2 P Kpatch D + 2 D E per sample."""
-    return layers * S * (24 * width * width + 4 * S * width) + 2 * P * kpatch * width + 2 * width * embed
+def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=False):
+    """L*S*(24 D^2 + 4 S D) + 2 P Kpatch D + 2 D E per sample.  With `running.last_block_rows` the last block
+    is evaluated on the one row per item the read-out takes: its key / value projection sees every token (4 S D^2), everything
+    else one row (24 D^2 - 4 D^2 + 4 S D) -- the work the step then actually needs, and what is counted."""
+    full = S * (24 * width * width + 4 * S * width)
+    last = 4 * S * width * width + 20 * width * width + 4 * S * width if (last_block_rows and layers > 0) else full
+    return (layers - 1) * full + last + 2 * P * kpatch * width + 2 * width * embed if layers > 0 else 2 * P * kpatch * width + 2 * width * embed
 
 
 PMC_FILE = "profiles/r3_pmc_traffic.json"
@@ -66,6 +70,9 @@ def parse():
     ap.add_argument("--stream", choices=["fp32", "fp16"], default=None,
                     help="running.stream_dtype: precision of the residual stream inside the transformer stacks (default: the "
                          "framework's default)")
+    ap.add_argument("--full-last-block", action="store_true",
+                    help="running.last_block_rows=False: evaluate the towers' last block on every token, as the reference does before "
+                         "its read-out discards all rows but one (default: on the read-out rows only -- exact, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
@@ -203,7 +210,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
           f"running.imagine=False model.loss.va=False model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} +running.negatives=local "
           f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
-          + (f"running.stream_dtype={args.stream} " if args.stream else "") +
+          + (f"running.stream_dtype={args.stream} " if args.stream else "") + f"running.last_block_rows={not args.full_last_block} " +
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
           f"running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -239,8 +246,9 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
     ms = dt / args.steps * 1e3
     S = mon.model.audio_head.misc.positional_embedding.shape[0]
     # algorithmic work of the step (recomputation and the micro-batch pre-pass are NOT counted as work done)
-    algo_flops = b * (3 * tower_fwd_flops(S, 1024, S - 1, width=args.width, layers=args.layers)
-                      + 12 * 77 * (24 * 512 * 512 + 4 * 77 * 512) + 2 * 512 * E) + 6.0 * b * b * E
+    lbr = not args.full_last_block
+    algo_flops = b * (3 * tower_fwd_flops(S, 1024, S - 1, width=args.width, layers=args.layers, last_block_rows=lbr)
+                      + tower_fwd_flops(77, 0, 0, width=512, layers=12, last_block_rows=lbr)) + 6.0 * b * b * E
     out = {"metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "e4m3 NT contractions, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
@@ -249,7 +257,8 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
                                   "negatives (BASELINE.json configs[2]; configs[4]'s tower with --width 1024 --layers 24, bf16 weights); "
                                   "NOT the headline configuration",
                       "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local",
-                      "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch), "fp8_gemm": bool(args.fp8)},
+                      "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch), "fp8_gemm": bool(args.fp8),
+                      "last_block": "read-out rows only (exact)" if lbr else "every token"},
            "loss": round(float(loss.detach()), 4), "step_tflops": round(algo_flops / (ms * 1e-3) / 1e12, 1),
            "step_mfma_frac": round(algo_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
@@ -292,7 +301,7 @@ def main():
           f"model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers={min(args.layers, 12)} "
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} "
           f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
-          + (f"running.stream_dtype={args.stream} " if args.stream else "") +
+          + (f"running.stream_dtype={args.stream} " if args.stream else "") + f"running.last_block_rows={not args.full_last_block} " +
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} "
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
@@ -339,8 +348,9 @@ def main():
     kern_flops = 2.0 * Mrows * (4 * W) * W
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     P = S - 1
-    step_flops = b * (3 * tower_fwd_flops(S, 1024, P, width=W, layers=args.layers)
-                      + tower_fwd_flops(50, 3072, 49, layers=min(args.layers, 12))) + 6.0 * (b * world) ** 2 * E / world
+    lbr = not args.full_last_block
+    step_flops = b * (3 * tower_fwd_flops(S, 1024, P, width=W, layers=args.layers, last_block_rows=lbr)
+                      + tower_fwd_flops(50, 3072, 49, layers=min(args.layers, 12), last_block_rows=lbr)) + 6.0 * (b * world) ** 2 * E / world
     out = {
         "metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -349,7 +359,9 @@ def main():
         "config": {"workload": f"VA pretrain step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-{'B' if W == 768 else W}/{args.layers}L "
                                "fwd+bwd + frozen CLIP ViT-B/32 image tower fwd + InfoNCE + LARS (BASELINE.json configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",
-                   "negatives": "global (all-gather)" if world > 1 else "global"},
+                   "negatives": "global (all-gather)" if world > 1 else "global",
+                   # every feature and gradient is what the full block gives; --full-last-block computes the discarded rows too
+                   "last_block": "read-out rows only (exact dead-row elimination)" if lbr else "every token"},
         "loss": round(float(loss.detach()), 4),
         "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

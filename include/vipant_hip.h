@@ -111,6 +111,27 @@ int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t*
                        float* delta, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H, int32_t causal,
                        void* stream);
 
+/* ---- the same attention for ONE query per (item, head): the last block of a tower on its read-out rows ----------
+ * Both read-outs take one token per item from the stack's output (the class token, cvap/module/val.py:288-289; the
+ * end-of-text token, val.py:143-145), so only that row of the last block's output is ever read and only it carries a
+ * gradient: the block's per-token work runs on `batch` rows, and its attention has one query per (item, head) against all
+ * keys (exact: dead rows eliminated, nothing approximated).  Row of item i: i * S + idx[i] (idx == NULL: the first row).
+ * q_rows bf16 [batch, D]: the projected queries of those rows; qkv bf16 [batch*S, 3*D]: only its K and V column blocks are
+ * read; causal: keys <= the row.  out_rows bf16 [batch, D]; probs fp32 [batch, H, S]: the softmax rows, saved for backward. */
+int32_t vipant_mha_rows_fwd(const uint16_t* q_rows, const uint16_t* qkv, const int64_t* idx, uint16_t* out_rows, float* probs,
+                            int64_t batch, int64_t S, int64_t H, int32_t causal, void* stream);
+/* dq_rows bf16 [batch, D]; dK / dV of EVERY key row written into the K / V column blocks of dqkv bf16 [batch*S, 3*D] (zero
+ * rows behind a causal limit); the Q column block of dqkv is not touched. */
+int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const int64_t* idx, const float* probs,
+                            const uint16_t* dout_rows, uint16_t* dq_rows, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H,
+                            int32_t causal, void* stream);
+/* dst row i <- src row (i * rows_per_item + idx[i]) (idx == NULL: + 0); rows of row_bytes bytes, a multiple of 16. */
+int32_t vipant_gather_rows_bytes(const void* src, const int64_t* idx, void* dst, int64_t n, int64_t rows_per_item, int64_t row_bytes,
+                           void* stream);
+/* x bf16 [*, D]: row (i * rows_per_item + idx[i]) <- bf16(row + add row i); add compact [n, D], fp32 (add_is_f32) or bf16. */
+int32_t vipant_add_rows_bf16(uint16_t* x, const int64_t* idx, const void* add, int32_t add_is_f32, int64_t n,
+                             int64_t rows_per_item, int64_t D, void* stream);
+
 /* ---- elementwise / layout helpers ------------------------------------------------------------------
  * fp32 -> bf16 cast of a [R, C] matrix; dst_t (optional) receives the transpose [C, R]. */
 int32_t vipant_cast_bf16(const float* src, uint16_t* dst, uint16_t* dst_t, int64_t R, int64_t C, void* stream);

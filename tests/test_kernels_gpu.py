@@ -355,6 +355,61 @@ def test_mha_spiky_scores(ops):
     assert_close(lse, rlse, 1e-4, 1e-3, "mha spiky lse")
 
 
+@pytest.mark.parametrize("batch,S,H,causal,with_idx", [(3, 316, 12, False, False), (4, 77, 8, True, True), (2, 50, 12, False, True),
+                                                       (5, 17, 2, True, False), (2, 645, 4, False, False)])
+def test_mha_rows(ops, batch, S, H, causal, with_idx):
+    """One query per (item, head) -- the last block on its read-out rows (csrc/readout_rows.hip) -- against the full attention of
+    the reference op (cvap/module/val.py:511-517) evaluated in fp64 and read at those rows: output, softmax rows, dq, dK, dV."""
+    D = H * 64
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    idx = torch.randint(0, S, (batch,), generator=g).to(DEV) if with_idx else None
+    if with_idx and causal:
+        idx[0] = S - 1; idx[1] = 0          # the whole sequence / a single key
+    r = (torch.arange(batch, device=DEV) * S + (idx if idx is not None else 0))
+    qkv = rnd(batch * S, 3 * D, seed=1, dtype=torch.bfloat16, scale=1.5)
+    q_rows = qkv[r, :D].contiguous()
+    out = torch.empty(batch, D, dtype=torch.bfloat16, device=DEV)
+    probs = torch.empty(batch, H, S, dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ops.call("vipant_mha_rows_fwd", q_rows.data_ptr(), qkv.data_ptr(), idx.data_ptr() if idx is not None else None, out.data_ptr(),
+             probs.data_ptr(), batch, S, H, int(causal), st)
+    qr = qkv.double().requires_grad_()
+    ref, _ = ref_attention(qr, batch, S, H, causal)
+    assert_close(out, ref[r], 1e-2, 1e-2, "mha_rows fwd")
+    assert_close(probs.sum(-1), torch.ones(batch, H), 1e-5, 1e-5, "softmax rows sum to one")
+    dout_rows = rnd(batch, D, seed=2, dtype=torch.bfloat16)
+    dfull = torch.zeros(batch * S, D, dtype=torch.float64, device=DEV)
+    dfull[r] = dout_rows.double()
+    ref.backward(dfull)
+    dq = torch.empty(batch, D, dtype=torch.bfloat16, device=DEV)
+    dqkv = torch.full((batch * S, 3 * D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.call("vipant_mha_rows_bwd", q_rows.data_ptr(), qkv.data_ptr(), idx.data_ptr() if idx is not None else None, probs.data_ptr(),
+             dout_rows.data_ptr(), dq.data_ptr(), dqkv.data_ptr(), batch, S, H, int(causal), st)
+    scale = qr.grad.abs().max().item()
+    assert_close(dq, qr.grad[r, :D], 2e-2, 2e-2 * scale, "mha_rows dq")
+    assert_close(dqkv[:, D:], qr.grad[:, D:], 2e-2, 2e-2 * scale, "mha_rows dK | dV")
+    assert bool((dqkv[:, :D] == 7.0).all()), "the Q column block is not this kernel's to write"
+    mask = torch.ones(batch * S, dtype=torch.bool, device=DEV); mask[r] = False
+    assert float(qr.grad[:, :D][mask].abs().max()) == 0.0        # the premise: no query gradient off the read-out rows
+
+
+def test_gather_and_add_rows(ops):
+    batch, S, D = 5, 9, 768
+    idx = torch.tensor([0, 8, 3, 3, 7], device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    r = torch.arange(batch, device=DEV) * S + idx
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        x = rnd(batch * S, D, seed=3).to(dt)
+        assert torch.equal(ops.gather_rows(x, idx, batch, S), x[r])
+        assert torch.equal(ops.gather_rows(x, None, batch, S), x[::S])
+    x = rnd(batch * S, D, seed=4, dtype=torch.bfloat16)
+    for add in (rnd(batch, D, seed=5), rnd(batch, D, seed=6, dtype=torch.bfloat16)):
+        y = x.clone()
+        ops.call("vipant_add_rows_bf16", y.data_ptr(), idx.data_ptr(), add.data_ptr(), int(add.dtype == torch.float32), batch, S, D, st)
+        ref = x.clone(); ref[r] = (x[r].float() + add.float()).to(torch.bfloat16)
+        assert torch.equal(y, ref)
+
+
 # ------------------------------------------------------------------------------------------ layout helpers
 def test_cast_transpose(ops):
     for R, C in ((768, 3072), (2304, 768), (100, 36), (768, 512)):

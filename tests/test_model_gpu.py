@@ -306,6 +306,47 @@ def test_node_handoff_with_other_consumers(M, monkeypatch):
         assert rel_l2(g1[k], g0[k]) < 2e-3, (k, rel_l2(g1[k], g0[k]))     # bf16 rounding of (a + b) vs a, b separately
 
 
+def _tower_step(M, kind, last_block_rows, layers):
+    """One loss + backward through a trainable tower; returns (features, loss, gradients)."""
+    from vipant_amd import ops
+    if kind == "audio":
+        b = 6
+        head = M.build_audio_head(audio_cfg(256, 64, layers))
+        S = head.misc.positional_embedding.shape[0]
+        head.load_state_dict(gen.det_weights("e2e/L2", gen.vit_head_shapes(768, layers, 512, S)), strict=True)
+        x = gen.det_randn("rows/aud", (b, 1, 256, 64)).to(DEV)
+    else:
+        b = 5
+        head = M.build_text_head(text_cfg(layers))
+        head.load_state_dict(gen.det_weights("text/l2", gen.text_head_shapes(512, layers, 512)), strict=True)
+        x = gen.det_tokens("rows/tok", b).to(DEV)
+    lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
+    head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
+    head.encoder.last_block_rows = last_block_rows
+    other = ops.l2_normalize(gen.det_randn(f"rows/other/{kind}", (b, 512)).to(DEV))
+    feat = head(x, normalized=True)
+    loss = lhead(other, feat, None, normalized=True)
+    loss.backward()
+    return feat.detach(), float(loss), {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("kind,layers", [("audio", 2), ("audio", 1), ("text", 2)])
+def test_last_block_on_readout_rows_matches_full_block(M, kind, layers):
+    """`running.last_block_rows` (ops.BackboneFn `rows`): the last block evaluated on the read-out rows only -- class token of the
+    audio ViT, end-of-text token of the causal text tower -- against the full block: same features, loss and gradient of EVERY
+    parameter (the last block's included), up to the rounding of a different summation order."""
+    f0, l0, g0 = _tower_step(M, kind, False, layers)
+    f1, l1, g1 = _tower_step(M, kind, True, layers)
+    assert rel_err(f1, f0) < 4e-3, rel_err(f1, f0)
+    assert abs(l1 - l0) < 2e-3, (l0, l1)
+    assert sorted(g0) == sorted(g1)
+    worst = max((rel_l2(g1[k], g0[k]), k) for k in g0)
+    observe(f"last_block_rows_{kind}_L{layers}:{worst[1]}", feat_rel_err=rel_err(f1, f0), loss_abs_diff=abs(l1 - l0),
+            worst_grad_rel_l2=worst[0])
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) < 2e-2, (k, rel_l2(g1[k], g0[k]))
+
+
 @pytest.mark.parametrize("tag,L,b,T,Fq", [("L12", 12, 32, 256, 64), ("cfg2", 12, 64, 1024, 128)])
 def test_end_to_end_golden_e4m3(M, golden, tag, L, b, T, Fq):
     """`running.fp8_gemm` (BASELINE.json configs[4]) against the REFERENCE's own outputs, not against the bf16 HIP run: the same

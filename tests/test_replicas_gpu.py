@@ -171,7 +171,7 @@ def _run_at_local(rank, world, port, out):
         from vipant_amd.config import compose
         from vipant_amd.module import adjust_learning_rate
         from vipant_amd.monitor import VALMonitor
-        cfg = compose(AT_OV)
+        cfg = compose(AT_OV + ([f"seed={os.environ['VIPANT_TEST_SEED']}"] if os.environ.get("VIPANT_TEST_SEED") else []))
         cfg.rank = rank                              # the synthetic loader seeds per rank: every replica has its own batch
         torch.cuda.set_device(0)
         torch.manual_seed(cfg.seed)
@@ -231,10 +231,15 @@ def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path):
         ratio = float(d_hip.norm() / d_ref.norm())
         assert abs(ratio - 1) < 6e-2, (k, ratio)                         # bf16 towers: a few % on a gradient norm; never 2x
         dirs.append(float((d_hip - d_ref).norm() / d_ref.norm()))
+        if os.environ.get("VIPANT_TEST_VERBOSE"): print("DIR %-60s %.4f" % (k, dirs[-1]))
     dirs.sort()
-    # update direction: bf16 towers against the fp32 oracle at b = 8 -- typical tensor a few %, the noisiest (near-cancelling
-    # bias gradients) observed at 0.20
-    assert dirs[len(dirs) // 2] < 5e-2 and dirs[-1] < 0.3, (dirs[len(dirs) // 2], dirs[-1])
+    # update direction: bf16 towers against the fp32 oracle at b = 8.  Every tensor's error is dominated by ONE shared draw -- the
+    # error of d loss / d features, the feature noise amplified by the logit scale -- so the median moves as a whole with the
+    # rounding pattern: observed over six seeds (VIPANT_TEST_SEED) 0.021 ... 0.044 with the full last block and 0.021 ... 0.066 with
+    # `running.last_block_rows` (this seed: 0.044 / 0.066, the noisiest of the six in both modes); the noisiest tensor
+    # (near-cancelling LayerNorm-weight / bias gradients) 0.08 ... 0.23
+    print("update-direction error vs the fp32 oracle: median %.4f max %.4f" % (dirs[len(dirs) // 2], dirs[-1]))
+    assert dirs[len(dirs) // 2] < 8e-2 and dirs[-1] < 0.3, (dirs[len(dirs) // 2], dirs[-1])
 
 
 @pytest.mark.timeout(900)

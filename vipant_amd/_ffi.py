@@ -47,6 +47,10 @@ PROTOTYPES = {
     "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mha_rows_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mha_rows_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_gather_rows_bytes": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "vipant_add_rows_bf16": (_i32, [_p, _p, _p, _i32, _i64, _i64, _i64, _p]),
     "vipant_cast_bf16_multi": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "vipant_cast_f32": (_i32, [_p, _p, _i64, _p]),
     "vipant_quant_e4m3_rows": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),

@@ -26,7 +26,7 @@ _running_common = {
     "synthetic": True, "synthetic_steps": 8, "precomputed_image": False,
     # activation-memory plan for batches that do not fit: towers in micro-batches under one global-batch loss,
     # and / or the MLP activations recomputed in the backward
-    "micro_batch": 0, "recompute_mlp": False, "fp8_gemm": False, "stream_dtype": "fp16", "grad_stream": None,
+    "micro_batch": 0, "recompute_mlp": False, "fp8_gemm": False, "stream_dtype": "fp16", "grad_stream": None, "last_block_rows": True,
 }
 
 GROUPS = {

@@ -1,0 +1,258 @@
+// The last block of a tower evaluated on its READ-OUT ROWS only.
+//
+// Both read-outs of the path take one token per item from the stack's output -- ViTPostEncoder the class token
+// (cvap/module/val.py:288-289), GPTPostEncoder the end-of-text token (val.py:143-145) -- so of the LAST block's output only
+// `batch` of its `batch * S` rows are ever read, and only those rows carry a gradient.  Everything of that block that is per-token
+// (out_proj, ln_2, the MLP, the query projection) therefore needs `batch` rows, forward and backward; what needs all tokens is
+// ln_1 and the key / value projection (the read-out row attends to every token).  The attention itself is one query per
+// (item, head): the two kernels here.  Results are those of the full block on the read-out rows (dead rows eliminated, nothing
+// approximated); the contractions around them are the library's ordinary ones on `batch` rows (vipant_amd/ops.py, BackboneFn).
+//
+// HBM-bound streaming work: one wave per (item, head); phase 1 has a lane per key (the 128-byte K / V row of the head is one
+// cache line per lane), phase 2 a lane per head dimension (128 bytes per key across the wave).
+#include "common.h"
+
+namespace {
+
+constexpr int RW = 4;                 // waves (= (item, head) pairs) per workgroup
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ void load_row64(const bf16_t* p, float (&v)[64]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 t = *(const bf16x8*)(p + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c * 8 + e] = (float)t[e];
+    }
+}
+__device__ __forceinline__ float dot_row64(const bf16_t* p, const float (&v)[64]) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 t = *(const bf16x8*)(p + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            a0 = __builtin_fmaf((float)t[e], v[c * 8 + e], a0);
+            a1 = __builtin_fmaf((float)t[e + 1], v[c * 8 + e + 1], a1);
+        }
+    }
+    return a0 + a1;
+}
+
+// out_rows[i, h*64 ..] = softmax(q_i,h . K_i,h^T / 8 [keys <= row, if causal]) V_i,h;  probs[i, h, :] = that softmax (fp32)
+__global__ __launch_bounds__(RW * 64) void mha_rows_fwd_kernel(const bf16_t* __restrict__ q_rows, const bf16_t* __restrict__ qkv,
+                                                               const int64_t* __restrict__ idx, bf16_t* __restrict__ out_rows,
+                                                               float* __restrict__ probs, int batch, int S, int H, int causal) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * RW + wave;
+    const bool active = pair < batch * H;
+    const int i = active ? pair / H : 0, h = active ? pair % H : 0;
+    const int D = H * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int nkeys = causal ? (int)(idx != nullptr ? idx[i] : 0) + 1 : S;
+    float* sc = sm + wave * S;
+    const bf16_t* kbase = qkv + (int64_t)i * S * ld + D + h * 64;
+    if (active) {
+        float q[64];
+        load_row64(q_rows + (int64_t)i * D + h * 64, q);
+        float mx = -INFINITY;
+        for (int j = lane; j < S; j += 64) {
+            float s = -INFINITY;
+            if (j < nkeys) s = dot_row64(kbase + j * ld, q) * 0.125f;
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < S; j += 64) {
+            const float p = j < nkeys ? __builtin_amdgcn_exp2f((sc[j] - mx) * LOG2E) : 0.f;
+            sc[j] = p;
+            sum += p;
+        }
+        const float inv = 1.0f / wave_sum(sum);
+        for (int j = lane; j < S; j += 64) {
+            const float p = sc[j] * inv;
+            sc[j] = p;
+            probs[(int64_t)pair * S + j] = p;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const bf16_t* vp = kbase + D + lane;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= nkeys; j += 4) {
+            a0 = __builtin_fmaf(sc[j], (float)vp[j * ld], a0);
+            a1 = __builtin_fmaf(sc[j + 1], (float)vp[(j + 1) * ld], a1);
+            a2 = __builtin_fmaf(sc[j + 2], (float)vp[(j + 2) * ld], a2);
+            a3 = __builtin_fmaf(sc[j + 3], (float)vp[(j + 3) * ld], a3);
+        }
+        for (; j < nkeys; ++j) a0 = __builtin_fmaf(sc[j], (float)vp[j * ld], a0);
+        out_rows[(int64_t)i * D + h * 64 + lane] = (bf16_t)((a0 + a1) + (a2 + a3));
+    }
+}
+
+// Backward of the above for one query per (item, head): with dp_j = do . V_j and delta = sum_j p_j dp_j (= do . o),
+//   dV_j = p_j do,  ds_j = p_j (dp_j - delta),  dK_j = ds_j q / 8,  dq = sum_j ds_j K_j / 8.
+// dK / dV are written for EVERY key row of the item (zero rows behind a causal limit) into the K and V column blocks of
+// dqkv [batch * S, 3 D]; its Q column block is not touched (the query gradient exists for the read-out rows only: dq_rows).
+__global__ __launch_bounds__(RW * 64) void mha_rows_bwd_kernel(const bf16_t* __restrict__ q_rows, const bf16_t* __restrict__ qkv,
+                                                               const int64_t* __restrict__ idx, const float* __restrict__ probs,
+                                                               const bf16_t* __restrict__ dout_rows, bf16_t* __restrict__ dq_rows,
+                                                               bf16_t* __restrict__ dqkv, int batch, int S, int H, int causal) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * RW + wave;
+    const bool active = pair < batch * H;
+    const int i = active ? pair / H : 0, h = active ? pair % H : 0;
+    const int D = H * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int nkeys = causal ? (int)(idx != nullptr ? idx[i] : 0) + 1 : S;
+    float* sc = sm + wave * S;
+    const int64_t base = (int64_t)i * S * ld + D + h * 64;
+    const bf16_t* kbase = qkv + base;
+    if (active) {
+        float dov[64];
+        load_row64(dout_rows + (int64_t)i * D + h * 64, dov);
+        const float* pr = probs + (int64_t)pair * S;
+        float dl = 0.f;
+        for (int j = lane; j < nkeys; j += 64) {
+            const float dp = dot_row64(kbase + D + j * ld, dov);
+            sc[j] = dp;
+            dl = __builtin_fmaf(pr[j], dp, dl);
+        }
+        const float delta = wave_sum(dl);
+        float qv[64];
+        load_row64(q_rows + (int64_t)i * D + h * 64, qv);
+        for (int j = lane; j < S; j += 64) {
+            const float p = j < nkeys ? pr[j] : 0.f;
+            const float ds = j < nkeys ? p * (sc[j] - delta) * 0.125f : 0.f;
+            bf16_t* dk = dqkv + base + j * ld;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                bf16x8 tk, tv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tk[e] = (bf16_t)(ds * qv[c * 8 + e]);
+                    tv[e] = (bf16_t)(p * dov[c * 8 + e]);
+                }
+                *(bf16x8*)(dk + c * 8) = tk;
+                *(bf16x8*)(dk + D + c * 8) = tv;
+            }
+            sc[j] = ds;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const bf16_t* kp = kbase + lane;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= nkeys; j += 4) {
+            a0 = __builtin_fmaf(sc[j], (float)kp[j * ld], a0);
+            a1 = __builtin_fmaf(sc[j + 1], (float)kp[(j + 1) * ld], a1);
+            a2 = __builtin_fmaf(sc[j + 2], (float)kp[(j + 2) * ld], a2);
+            a3 = __builtin_fmaf(sc[j + 3], (float)kp[(j + 3) * ld], a3);
+        }
+        for (; j < nkeys; ++j) a0 = __builtin_fmaf(sc[j], (float)kp[j * ld], a0);
+        dq_rows[(int64_t)i * D + h * 64 + lane] = (bf16_t)((a0 + a1) + (a2 + a3));
+    }
+}
+
+// dst row i <- src row i * rpi + idx[i] (idx == NULL: + 0), rows of `row_bytes` bytes (multiple of 16): one wave per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          char* __restrict__ dst, int64_t n, int64_t rpi, int64_t row_bytes) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        for (int64_t c = (int64_t)lane * 16; c < row_bytes; c += 64 * 16)
+            *(u32x4*)(dst + i * row_bytes + c) = *(const u32x4*)(src + r * row_bytes + c);
+    }
+}
+
+// x row (i * rpi + idx[i]) <- bf16(x row + add row i);  add fp32 (ADD_F32) or bf16, compact [n, D]
+template <bool ADD_F32>
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ x, const int64_t* __restrict__ idx,
+                                                       const void* __restrict__ add, int64_t n, int64_t rpi, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        for (int c = lane * 4; c < D; c += 256) {
+            bf16x4* px = (bf16x4*)(x + r * D + c);
+            const bf16x4 v = *px;
+            f32x4 a;
+            if (ADD_F32) {
+                a = *(const f32x4*)((const float*)add + i * D + c);
+            } else {
+                const bf16x4 t = *(const bf16x4*)((const bf16_t*)add + i * D + c);
+                a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            }
+            *px = f32x4_to_bf16x4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]} + a);
+        }
+    }
+}
+
+int32_t check_rows(const void* q_rows, const void* qkv, int64_t batch, int64_t S, int64_t H) {
+    VIPANT_REQUIRE(q_rows != nullptr && qkv != nullptr, VIPANT_EBADSHAPE, "mha_rows: null operand");
+    VIPANT_REQUIRE(batch > 0 && S > 0 && H > 0 && S <= 4096 && batch * H < (1ll << 31) - RW, VIPANT_EBADSHAPE,
+                   "mha_rows: bad shape batch=%ld S=%ld H=%ld (S <= 4096)", (long)batch, (long)S, (long)H);
+    VIPANT_REQUIRE((uintptr_t)q_rows % 16 == 0 && (uintptr_t)qkv % 16 == 0, VIPANT_EALIGN, "mha_rows: operands must be 16-byte aligned");
+    return VIPANT_OK;
+}
+
+unsigned rows_grid(int64_t n) {
+    const int64_t g = ceil_div(n, 4);
+    return (unsigned)(g < 4096 ? g : 4096);
+}
+
+}  // namespace
+
+extern "C" int32_t vipant_mha_rows_fwd(const uint16_t* q_rows, const uint16_t* qkv, const int64_t* idx, uint16_t* out_rows,
+                                       float* probs, int64_t batch, int64_t S, int64_t H, int32_t causal, void* stream) {
+    if (int32_t e = check_rows(q_rows, qkv, batch, S, H)) return e;
+    VIPANT_REQUIRE(out_rows != nullptr && probs != nullptr, VIPANT_EBADSHAPE, "mha_rows_fwd: null output");
+    hipLaunchKernelGGL(mha_rows_fwd_kernel, dim3((unsigned)ceil_div(batch * H, RW)), dim3(RW * 64), (size_t)RW * S * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)q_rows, (const bf16_t*)qkv, idx, (bf16_t*)out_rows, probs, (int)batch,
+                       (int)S, (int)H, (int)causal);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const int64_t* idx, const float* probs,
+                                       const uint16_t* dout_rows, uint16_t* dq_rows, uint16_t* dqkv, int64_t batch, int64_t S,
+                                       int64_t H, int32_t causal, void* stream) {
+    if (int32_t e = check_rows(q_rows, qkv, batch, S, H)) return e;
+    VIPANT_REQUIRE(probs != nullptr && dout_rows != nullptr && dq_rows != nullptr && dqkv != nullptr, VIPANT_EBADSHAPE,
+                   "mha_rows_bwd: null operand");
+    VIPANT_REQUIRE((uintptr_t)dout_rows % 16 == 0 && (uintptr_t)dqkv % 16 == 0, VIPANT_EALIGN,
+                   "mha_rows_bwd: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(mha_rows_bwd_kernel, dim3((unsigned)ceil_div(batch * H, RW)), dim3(RW * 64), (size_t)RW * S * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)q_rows, (const bf16_t*)qkv, idx, probs, (const bf16_t*)dout_rows,
+                       (bf16_t*)dq_rows, (bf16_t*)dqkv, (int)batch, (int)S, (int)H, (int)causal);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_gather_rows_bytes(const void* src, const int64_t* idx, void* dst, int64_t n, int64_t rows_per_item,
+                                      int64_t row_bytes, void* stream) {
+    VIPANT_REQUIRE(n > 0 && rows_per_item > 0 && row_bytes > 0 && row_bytes % 16 == 0, VIPANT_EBADSHAPE,
+                   "gather_rows_bytes: need n > 0 and rows of a multiple of 16 bytes (row_bytes=%ld)", (long)row_bytes);
+    VIPANT_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, VIPANT_EALIGN, "gather_rows_bytes: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(n)), dim3(256), 0, (hipStream_t)stream, (const char*)src, idx, (char*)dst, n,
+                       rows_per_item, row_bytes);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_add_rows_bf16(uint16_t* x, const int64_t* idx, const void* add, int32_t add_is_f32, int64_t n,
+                                        int64_t rows_per_item, int64_t D, void* stream) {
+    VIPANT_REQUIRE(n > 0 && rows_per_item > 0 && D > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "add_rows_bf16: bad shape");
+    if (add_is_f32)
+        hipLaunchKernelGGL(add_rows_kernel<true>, dim3(rows_grid(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, idx, add, n,
+                           rows_per_item, (int)D);
+    else
+        hipLaunchKernelGGL(add_rows_kernel<false>, dim3(rows_grid(n)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, idx, add, n,
+                           rows_per_item, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}

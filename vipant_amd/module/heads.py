@@ -122,7 +122,13 @@ class MetaHead(nn.Module):
         x = self.pre_encoder(x, **kwargs)                        # (N, L, D)
         x = self.pre_encoder_addon(x, **kwargs)
         x = x.permute(1, 0, 2) if not self.encoder.batch_first else x
-        x = self.encoder(x, **kwargs)
+        # the read-out takes one row per item (class / end-of-text token): tell the stack, which then evaluates its last block on
+        # those rows only and returns them (exact; `running.last_block_rows`).  Only when nothing sits between stack and read-out.
+        rows = None
+        if (self.encoder.batch_first and hasattr(self.post_encoder, "readout_rows") and not kwargs.get("require_feature", False)
+                and type(self.post_encoder_addon).__name__ == "AddonEncoder"):
+            rows = self.post_encoder.readout_rows(mask=self.pre_encoder.mask)
+        x = self.encoder(x, **dict(kwargs, rows=rows)) if rows is not None else self.encoder(x, **kwargs)
         x = x.permute(1, 0, 2) if not self.encoder.batch_first else x
         mask = self.pre_encoder.mask
         x = self.post_encoder_addon(x, **kwargs)

@@ -154,8 +154,14 @@ class GPTPostEncoder(MetaEncoder):
     def initialize_parameters(self):
         pass
 
+    def readout_rows(self, mask=None):
+        """The one row per item this read-out takes: the end-of-text index the pre-encoder recorded."""
+        return mask
+
     def forward(self, x, positional_embedding=None, class_embedding=None, mask=None, normalized=False, **kwargs):
         b, L, D = x.shape
+        if L == 1:          # the stack already returned the read-out rows
+            mask = None
         return ops.ReadoutFn.apply(x.reshape(b * L, D), mask, b, L,
                                    *ops.no_tape((self.ln.weight, self.ln.bias, self.proj)), bool(normalized))
 
@@ -271,6 +277,10 @@ class ViTPostEncoder(MetaEncoder):
     def initialize_parameters(self):
         pass
 
+    def readout_rows(self, mask=None):
+        """The one row per item this read-out takes: the class token."""
+        return "first"
+
     def forward(self, x, positional_embedding=None, class_embedding=None, position_resolution=None,
                 require_feature=False, normalized=False, **kwargs):
         if require_feature:
@@ -323,16 +333,21 @@ class TransformerBackbone(MetaEncoder):
         self.recompute_mlp = False  # `running.recompute_mlp`: do not keep the [M, 4D] MLP activations for the backward
         self.fp8 = False            # `running.fp8_gemm`: e4m3 operands in the NT contractions of the trainable blocks (configs[4])
         self.stream_f16 = True      # `running.stream_dtype` (fp16 | fp32): residual stream inside the stack in the reference's autocast precision
+        self.last_block_rows = True     # `running.last_block_rows`: honour `rows=` (the last block on the read-out rows only; exact)
 
     def build_attention_mask(self):
         """Marker only: the -inf upper-triangular mask (val.py:484-491) is applied inside the attention kernel."""
         return None if self.ctx_len is None else "causal"
 
-    def forward(self, x, **kwargs):
+    def forward(self, x, rows=None, **kwargs):
+        """`rows` (None | "first" | int64 [b]): the one row per item the caller is going to read (MetaHead asks its post-encoder):
+        the stack then returns [b, 1, D] -- those rows -- and evaluates its last block on them alone (ops.BackboneFn)."""
         b, S, D = x.shape
         if self.causal and S > self.ctx_len:
             raise ValueError(f"sequence length {S} exceeds ctx_len {self.ctx_len}")
         params = [p for blk in self.resblocks for p in blk.flat_params()]
+        if not self.last_block_rows or len(params) == 0:
+            rows = None
         out = ops.BackboneFn.apply(x.reshape(b * S, D), b, S, self.causal, self.grad_sync, self.recompute_mlp, self.fp8,
-                                   self.stream_f16, *ops.no_tape(params))
-        return out.view(b, S, D)
+                                   self.stream_f16, rows, *ops.no_tape(params))
+        return out.view(b, S if rows is None else 1, D)

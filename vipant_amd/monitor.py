@@ -95,9 +95,13 @@ class Monitor(object):
         # the residual stream inside every transformer stack: fp16 (the reference's autocast precision; default) or fp32;
         # LayerNorm statistics are fp32 either way
         stream_f16 = str(cfg.running.get("stream_dtype", "fp16")).lower() in ("fp16", "float16", "half")
+        # `running.last_block_rows` (default on): a tower's last block is evaluated on the rows its read-out takes (class / end-of-text
+        # token) -- exact, see ops.BackboneFn; off: the full block, as the reference computes it before discarding the other rows
+        last_rows = bool(cfg.running.get("last_block_rows", True)) and os.environ.get("VIPANT_LAST_BLOCK_ROWS", "1") != "0"
         for head in (model.audio_head, model.image_head, model.text_head):
             if head is not None and hasattr(head, "encoder"):
                 head.encoder.stream_f16 = stream_f16
+                head.encoder.last_block_rows = last_rows
         if cfg.running.get("fp8_gemm", False):      # BASELINE.json configs[4]: e4m3 operands in the audio tower's NT contractions
             if model.audio_head is not None and hasattr(model.audio_head, "encoder"):
                 model.audio_head.encoder.fp8 = True

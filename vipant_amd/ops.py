@@ -174,6 +174,14 @@ def residual_add(x: torch.Tensor, add: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_rows(x: torch.Tensor, idx: Optional[torch.Tensor], batch: int, S: int) -> torch.Tensor:
+    """x [batch * S, D] (any 2- or 4-byte dtype) -> its rows i * S + idx[i] (idx None: the first row of every item), [batch, D]."""
+    assert x.dim() == 2 and x.is_contiguous() and x.shape[0] == batch * S
+    out = torch.empty((batch, x.shape[1]), dtype=x.dtype, device=x.device)
+    call("vipant_gather_rows_bytes", x.data_ptr(), _ptr(idx), out.data_ptr(), batch, S, x.shape[1] * x.element_size(), _stream())
+    return out
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=None, dx=None, lddx=None,
                   dx_bf16=None, dgamma, dbeta, dx_colsum=None, accumulate=False, rows=None, ldx=None):
     D = x.shape[-1]
@@ -441,15 +449,28 @@ class BackboneFn(torch.autograd.Function):
     residual stream x [batch*S, D].  One autograd node for the whole stack: the layer loop, the saved
     activations and the (fp32, bf16) gradient-stream pair between layers are managed here, not by autograd.
     Per block four entry points of the fused operator set each way (include/vipant_hip.h): vipant_ln_qkv_*, vipant_mha_*,
-    vipant_gemm_bias_residual_*, vipant_ln_mlp_quickgelu_*."""
+    vipant_gemm_bias_residual_*, vipant_ln_mlp_quickgelu_*.
+
+    `rows` (None | "first" | int64 [batch]): the caller will read ONE row per item of the output -- the class token
+    (ViTPostEncoder, cvap/module/val.py:288-289) or the end-of-text token (GPTPostEncoder, val.py:143-145) -- and the node returns
+    just those rows, [batch, D].  The last block is then evaluated on them alone (csrc/readout_rows.hip): ln_1 and the key / value
+    projection see every token, the query projection, the attention (one query per item and head), out_proj, ln_2 and the MLP see
+    `batch` rows, forward and backward.  Exact: the other rows of the last block's output are never read and carry no gradient, so
+    every feature and every parameter gradient is what the full block gives (tests/test_model_gpu.py, against the reference's
+    vectors and against rows=None)."""
 
     @staticmethod
-    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, stream_f16, *params):
+    def forward(ctx, x, batch, S, causal, grad_sync, recompute_mlp, fp8, stream_f16, rows, *params):
         _need(x, F32, "backbone.x")
         x_in = x
         M, D = x.shape
         assert M == batch * S and len(params) % 12 == 0
         L, H = len(params) // 12, D // 64
+        prune = rows is not None and L > 0
+        ridx = rows if isinstance(rows, torch.Tensor) else None
+        if ridx is not None:
+            _need(ridx, I64, "backbone.rows")
+            assert ridx.numel() == batch and ridx.is_contiguous()
         train = any(ctx.needs_input_grad)
         dev = x.device
         st = _stream()
@@ -498,13 +519,47 @@ class BackboneFn(torch.autograd.Function):
                 wqkv_t, wo_t, wfc_t, wpr_t = wt_all[4 * l:4 * l + 4]
                 wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None) +
                            ((wq_all[4 * l:4 * l + 4], wtq_all[4 * l:4 * l + 4]) if fp8 else (None, None)))
-                h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
-                mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
-                if keep_mlp:
-                    u, g = new(4 * D, torch.uint8), new(4 * D)
+                if prune and l == L - 1:         # the last block keeps its per-token activations for the read-out rows only
+                    h1, qkv = new(D), new(3 * D)
+                    mean1, rstd1 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(2))
+                else:
+                    h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
+                    mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
+                    if keep_mlp:
+                        u, g = new(4 * D, torch.uint8), new(4 * D)
             else:
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
+            if prune and l == L - 1:
+                # the last block on the read-out rows (bf16 contractions whatever `fp8` says: they are `batch`-row launches)
+                def newr(cols, dtype=BF16):
+                    return torch.empty((batch, cols), dtype=dtype, device=dev)
+                xs = new(D, SDT) if y_prev is not None else None
+                call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, ln1w.data_ptr(), ln1b.data_ptr(), h1.data_ptr(), None,
+                     mean1.data_ptr(), rstd1.data_ptr(), M, D, _ptr(y_prev), _ptr(xs), None, None, sflags(x), st)
+                if xs is not None:
+                    x = xs
+                gemm_nt(h1, wqkv_b[D:], qkv[:, D:], bias=bqkv[D:], epi=EPI_BF16)         # K, V of every token
+                h1_r = gather_rows(h1, ridx, batch, S)
+                q_r = gemm_nt(h1_r, wqkv_b[:D], newr(D), bias=bqkv[:D], epi=EPI_BF16)     # Q of the read-out rows
+                o_r, probs = newr(D), torch.empty((batch, H, S), dtype=F32, device=dev)
+                call("vipant_mha_rows_fwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), o_r.data_ptr(), probs.data_ptr(), batch, S, H,
+                     int(causal), st)
+                y1_r = gemm_nt(o_r, wo_b, newr(D), bias=bo, epi=EPI_BF16)
+                x_r = gather_rows(x, ridx, batch, S)
+                # the read-out rows' stream stays fp32 from here, and c_proj adds it in its epilogue: the rows the features are
+                # read from skip the two roundings (fp16 stream, bf16 branch output) the full block would give them
+                x1_r, h2_r, u_r, g_r = newr(D, F32), newr(D), newr(4 * D, torch.uint8), newr(4 * D)
+                mean2_r, rstd2_r = (torch.empty((batch,), dtype=F32, device=dev) for _ in range(2))
+                call("vipant_layernorm_fwd_e4m3", x_r.data_ptr(), D, ln2w.data_ptr(), ln2b.data_ptr(), h2_r.data_ptr(), None,
+                     mean2_r.data_ptr(), rstd2_r.data_ptr(), batch, D, y1_r.data_ptr(), x1_r.data_ptr(), None, None,
+                     _ffi.STREAM_IN_F16 if x_r.dtype == F16 else 0, st)
+                gemm_nt(h2_r, wfc_b, g_r, bias=bfc, aux=u_r, epi=EPI_QUICKGELU_D8)
+                out_r = gemm_nt(g_r, wpr_b, newr(D, F32), bias=bpr, aux=x1_r, epi=EPI_RESIDUAL_F32)
+                if train:
+                    saved += [x, mean1, rstd1, h1, qkv, q_r, probs, o_r, h1_r, x1_r, mean2_r, rstd2_r, h2_r, u_r, g_r]
+                x, y_prev = out_r, None
+                continue
             # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
             xs = new(D, SDT) if y_prev is not None else None
             call("vipant_ln_qkv_fwd_e4m3", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
@@ -536,7 +591,8 @@ class BackboneFn(torch.autograd.Function):
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
-            ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8)
+            ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8, prune)
+            ctx.rows = ridx
             ctx.grad_sync = grad_sync
             ctx._vipant_kind = "stack"
             ctx.readout_grad = None                      # (idx | None, compact fp32 rows), handed over by ReadoutFn.backward
@@ -545,20 +601,28 @@ class BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx_in):
-        batch, S, causal, L, H, recompute_mlp, fp8 = ctx.meta
+        batch, S, causal, L, H, recompute_mlp, fp8, prune = ctx.meta
+        ridx = ctx.rows
         tensors = ctx.saved_tensors
         ns = 11 if recompute_mlp else 13
-        saved, params = tensors[:ns * L], tensors[ns * L:]
+        nsaved = ns * (L - 1) + 15 if prune else ns * L
+        saved, params = tensors[:nsaved], tensors[nsaved:]
         dev = dx_in.device
         st = _stream()
-        M, D = dx_in.shape
+        M, D = batch * S, dx_in.shape[1]
         # Gradient of the residual stream.  Default: bf16 only -- the tensor the next contraction reads IS the stream (LayerNorm
         # backward 10 instead of 16 B per element); the forward stream stays fp32, so the loss and the features are untouched and
         # the gradients move from ~1.3 % to ~1.6 % rel-L2 of the fp32 reference (profiles/r2_stream_precision.md, model D; the
         # reference's own GPU path keeps this stream in fp16).  VIPANT_GRAD_STREAM=fp32: fp32 master + bf16 copy, both in place.
         handed, ctx.readout_grad = ctx.readout_grad, None
         top_rows = None
-        if handed is not None and _is_placeholder(dx_in) and not GRAD_STREAM_F32:
+        if prune:
+            # the gradient arrives for the read-out rows only, [batch, D]: dense, or handed over by the read-out node
+            if handed is not None:
+                dx_in = handed[1] if _is_placeholder(dx_in) else dx_in + handed[1]
+            dx, dx_b = None, None
+            dxr_b = cast_bf16_flat(dx_in.contiguous())
+        elif handed is not None and _is_placeholder(dx_in) and not GRAD_STREAM_F32:
             # the read-out's gradient as compact rows: they go straight into a zeroed bf16 stream gradient
             ridx, rows = handed
             dx = None
@@ -580,7 +644,8 @@ class BackboneFn(torch.autograd.Function):
         act = dyq = None
         if fp8:
             act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev))
-            dyq = quant_e4m3(dx_b)      # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
+            if not prune:
+                dyq = quant_e4m3(dx_b)      # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
         du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
         dh = torch.empty((M, D), dtype=BF16, device=dev)
         do = torch.empty((M, D), dtype=BF16, device=dev)
@@ -591,13 +656,56 @@ class BackboneFn(torch.autograd.Function):
         lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
         # d c_proj.bias of the top block (lower blocks get theirs from ln_1's backward): column sums of the stream gradient, which
         # with a handed-over read-out gradient has only those rows
-        colsum(top_rows if top_rows is not None else dx_b, lg.views[11])
+        colsum(dxr_b if prune else (top_rows if top_rows is not None else dx_b), lg.views[11])
         for l in reversed(range(L)):
-            x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             ln1w, _, _, _, _, _, ln2w, _, _, bfc, _, _ = (p.detach() for p in params[12 * l:12 * l + 12])
             wqkv_t, wo_t, wfc_t, wpr_t, wfc_b, wq4, wtq4 = ctx.wts[l]
             (d_ln1w, d_ln1b, d_wqkv, d_bqkv, d_wo, d_bo, d_ln2w, d_ln2b, d_wfc, d_bfc, d_wpr, d_bpr) = lg.views
             lg_below = _LayerGrads([p.shape for p in params[12 * (l - 1):12 * l]], dev) if l > 0 else None
+            if prune and l == L - 1:
+                # the last block on the read-out rows: the two block operators of the MLP / out_proj half on `batch` rows, the
+                # one-query attention backward, then the K / V half of in_proj and ln_1 on every token
+                x, mean1, rstd1, h1, qkv, q_r, probs, o_r, h1_r, x1_r, mean2_r, rstd2_r, h2_r, u_r, g_r = saved[nsaved - 15:]
+                du_r = torch.empty((batch, 4 * D), dtype=BF16, device=dev)
+                dh_r, do_r, dq_r = (torch.empty((batch, D), dtype=BF16, device=dev) for _ in range(3))
+                call("vipant_ln_mlp_quickgelu_bwd_e4m3", dxr_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u_r.data_ptr(),
+                     g_r.data_ptr(), h2_r.data_ptr(), x1_r.data_ptr(), mean2_r.data_ptr(), rstd2_r.data_ptr(), ln2w.data_ptr(), None,
+                     dxr_b.data_ptr(), du_r.data_ptr(), dh_r.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(),
+                     d_ln2w.data_ptr(), d_ln2b.data_ptr(), d_bo.data_ptr(), batch, D, ws.data_ptr(), ws.numel(), None,
+                     _ffi.STREAM_IN_F16 if x1_r.dtype == F16 else 0, st)
+                call("vipant_gemm_bias_residual_bwd_e4m3", dxr_b.data_ptr(), wo_t.data_ptr(), o_r.data_ptr(), do_r.data_ptr(),
+                     d_wo.data_ptr(), batch, D, D, ws.data_ptr(), ws.numel(), None, st)
+                dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+                call("vipant_mha_rows_bwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), probs.data_ptr(), do_r.data_ptr(),
+                     dq_r.data_ptr(), dqkv.data_ptr(), batch, S, H, int(causal), st)
+                # dh = dK|dV . W_kv on every token, + dq . W_q on the read-out rows
+                gemm_nt(dqkv[:, D:], wqkv_t[:, D:], dh, epi=EPI_BF16)
+                dhq = gemm_nt(dq_r, wqkv_t[:, :D], torch.empty((batch, D), dtype=F32, device=dev), epi=EPI_F32)
+                call("vipant_add_rows_bf16", dh.data_ptr(), _ptr(ridx), dhq.data_ptr(), 1, batch, S, D, st)
+                gemm_tn(dqkv[:, D:], h1, d_wqkv[D:], a_colsum=d_bqkv[D:], ws_name="block_bwd")
+                gemm_tn(dq_r, h1_r, d_wqkv[:D], a_colsum=d_bqkv[:D], ws_name="block_bwd")
+                del dqkv
+                # ln_1 backward on every token; the residual gradient of this block exists on the read-out rows only
+                dx_b = torch.empty((M, D), dtype=BF16, device=dev)
+                call("vipant_layernorm_bwd_e4m3", dh.data_ptr(), _ffi.LN_X_F16 if x.dtype == F16 else 0, x.data_ptr(), D,
+                     mean1.data_ptr(), rstd1.data_ptr(), ln1w.data_ptr(), None, None, D, dx_b.data_ptr(), d_ln1w.data_ptr(),
+                     d_ln1b.data_ptr(), lg_below.views[11].data_ptr() if lg_below is not None else None, 0, M, D, ws.data_ptr(),
+                     ws.numel(), None, None, st)
+                call("vipant_add_rows_bf16", dx_b.data_ptr(), _ptr(ridx), dxr_b.data_ptr(), 0, batch, S, D, st)
+                if lg_below is not None:
+                    colsum(dxr_b, lg_below.views[11], accumulate=True)
+                if GRAD_STREAM_F32:
+                    dx = torch.empty((M, D), dtype=F32, device=dev)
+                    call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
+                if fp8:
+                    dyq = quant_e4m3(dx_b)
+                for i, v in enumerate(lg.views):
+                    grads[12 * l + i] = v
+                if ctx.grad_sync is not None:
+                    ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
+                lg = lg_below
+                continue
+            x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             if recompute_mlp:
                 call("vipant_mlp_quickgelu_recompute_e4m3", h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(), g.data_ptr(),
                      M, D, C.byref(fp8_plan(wq4[2], None, act)) if fp8 else None, st)
@@ -636,8 +744,8 @@ class BackboneFn(torch.autograd.Function):
             else:
                 dx = torch.empty((M, D), dtype=F32, device=dev)
                 call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
-        out_grads = [gr if need[8 + i] else None for i, gr in enumerate(grads)]
-        return (dx if need[0] else None, None, None, None, None, None, None, None, *out_grads)
+        out_grads = [gr if need[9 + i] else None for i, gr in enumerate(grads)]
+        return (dx if need[0] else None, None, None, None, None, None, None, None, None, *out_grads)
 
 
 # ---------------------------------------------------------------------------------- read-out
