@@ -8,8 +8,8 @@
 // (item, head): the two kernels here.  Results are those of the full block on the read-out rows (dead rows eliminated, nothing
 // approximated); the contractions around them are the library's ordinary ones on `batch` rows (vipant_amd/ops.py, BackboneFn).
 //
-// HBM-bound streaming work: one wave per (item, head); phase 1 has a lane per key (the 128-byte K / V row of the head is one
-// cache line per lane), phase 2 a lane per head dimension (128 bytes per key across the wave).
+// HBM-bound streaming work: one wave per (item, head), eight lanes per key row, so every wave load / store covers eight whole
+// 128-byte rows of the head's K / V (or dK / dV) block.
 #include "common.h"
 
 namespace {
@@ -17,26 +17,28 @@ namespace {
 constexpr int RW = 4;                 // waves (= (item, head) pairs) per workgroup
 constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ void load_row64(const bf16_t* p, float (&v)[64]) {
+// Lane layout of the key phases: 8 lanes share a key row (lane & 7 = its 16-byte piece, 8 head dimensions), 8 keys per wave
+// instruction -- a wave load covers 8 whole 128-byte rows.  A dot product over the 64 dimensions is 8 FMAs per lane and a
+// 3-step butterfly over the 8 lanes of the key.
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 t = *(const bf16x8*)p;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 t = *(const bf16x8*)(p + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[c * 8 + e] = (float)t[e];
-    }
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
 }
-__device__ __forceinline__ float dot_row64(const bf16_t* p, const float (&v)[64]) {
-    float a0 = 0.f, a1 = 0.f;
+__device__ __forceinline__ float dot8(const float (&a)[8], const float (&b)[8]) {
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 t = *(const bf16x8*)(p + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            a0 = __builtin_fmaf((float)t[e], v[c * 8 + e], a0);
-            a1 = __builtin_fmaf((float)t[e + 1], v[c * 8 + e + 1], a1);
-        }
+    for (int e = 0; e < 8; e += 2) {
+        s0 = __builtin_fmaf(a[e], b[e], s0);
+        s1 = __builtin_fmaf(a[e + 1], b[e + 1], s1);
     }
-    return a0 + a1;
+    return s0 + s1;
+}
+__device__ __forceinline__ float sum8(float v) {        // over the 8 lanes of a key; every lane gets the sum
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
 }
 
 // out_rows[i, h*64 ..] = softmax(q_i,h . K_i,h^T / 8 [keys <= row, if causal]) V_i,h;  probs[i, h, :] = that softmax (fp32)
@@ -53,15 +55,29 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_fwd_kernel(const bf16_t* __r
     const int nkeys = causal ? (int)(idx != nullptr ? idx[i] : 0) + 1 : S;
     float* sc = sm + wave * S;
     const bf16_t* kbase = qkv + (int64_t)i * S * ld + D + h * 64;
+    const int kl = lane >> 3, piece = (lane & 7) * 8;
     if (active) {
-        float q[64];
-        load_row64(q_rows + (int64_t)i * D + h * 64, q);
+        float q[8];
+        load8(q_rows + (int64_t)i * D + h * 64 + piece, q);
         float mx = -INFINITY;
-        for (int j = lane; j < S; j += 64) {
-            float s = -INFINITY;
-            if (j < nkeys) s = dot_row64(kbase + j * ld, q) * 0.125f;
-            sc[j] = s;
-            mx = fmaxf(mx, s);
+        // four key groups (32 keys) per iteration, their loads issued together: the loop is bound by load latency otherwise
+        for (int j0 = 0; j0 < nkeys; j0 += 32) {
+            float kv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
+                if (j < nkeys) load8(kbase + j * ld + piece, kv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+                const float d = sum8(dot8(kv[u], q)) * 0.125f;
+                const float s = j < nkeys ? d : -INFINITY;
+                if ((lane & 7) == 0 && j < S) sc[j] = s;
+                mx = fmaxf(mx, s);
+            }
         }
         mx = wave_max(mx);
         float sum = 0.f;
@@ -79,17 +95,35 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_fwd_kernel(const bf16_t* __r
     }
     __syncthreads();
     if (active) {
-        const bf16_t* vp = kbase + D + lane;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int j = 0;
-        for (; j + 4 <= nkeys; j += 4) {
-            a0 = __builtin_fmaf(sc[j], (float)vp[j * ld], a0);
-            a1 = __builtin_fmaf(sc[j + 1], (float)vp[(j + 1) * ld], a1);
-            a2 = __builtin_fmaf(sc[j + 2], (float)vp[(j + 2) * ld], a2);
-            a3 = __builtin_fmaf(sc[j + 3], (float)vp[(j + 3) * ld], a3);
+        // o = sum_j p_j V_j: each lane accumulates its 8 dimensions over the keys j = kl (mod 8), then the 8 key groups are summed
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j0 = kl; j0 < nkeys; j0 += 32) {
+            float vv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
+                if (j0 + u * 8 < nkeys) load8(kbase + D + (j0 + u * 8) * ld + piece, vv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float p = j0 + u * 8 < nkeys ? sc[j0 + u * 8] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, vv[u][e], acc[e]);
+            }
         }
-        for (; j < nkeys; ++j) a0 = __builtin_fmaf(sc[j], (float)vp[j * ld], a0);
-        out_rows[(int64_t)i * D + h * 64 + lane] = (bf16_t)((a0 + a1) + (a2 + a3));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += __shfl_xor(acc[e], 8, 64);
+            acc[e] += __shfl_xor(acc[e], 16, 64);
+            acc[e] += __shfl_xor(acc[e], 32, 64);
+        }
+        if (kl == 0) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+            *(bf16x8*)(out_rows + (int64_t)i * D + h * 64 + piece) = o;
+        }
     }
 }
 
@@ -112,50 +146,80 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_bwd_kernel(const bf16_t* __r
     float* sc = sm + wave * S;
     const int64_t base = (int64_t)i * S * ld + D + h * 64;
     const bf16_t* kbase = qkv + base;
+    const int kl = lane >> 3, piece = (lane & 7) * 8;
     if (active) {
-        float dov[64];
-        load_row64(dout_rows + (int64_t)i * D + h * 64, dov);
+        float dov[8], qv[8];
+        load8(dout_rows + (int64_t)i * D + h * 64 + piece, dov);
+        load8(q_rows + (int64_t)i * D + h * 64 + piece, qv);
         const float* pr = probs + (int64_t)pair * S;
+        // dp_j = do . V_j for every key, delta = sum_j p_j dp_j
         float dl = 0.f;
-        for (int j = lane; j < nkeys; j += 64) {
-            const float dp = dot_row64(kbase + D + j * ld, dov);
-            sc[j] = dp;
-            dl = __builtin_fmaf(pr[j], dp, dl);
+        for (int j0 = 0; j0 < nkeys; j0 += 32) {
+            float vv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
+                if (j < nkeys) load8(kbase + D + j * ld + piece, vv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+                const float dp = sum8(dot8(vv[u], dov));
+                if ((lane & 7) == 0 && j < nkeys) {
+                    sc[j] = dp;
+                    dl = __builtin_fmaf(pr[j], dp, dl);
+                }
+            }
         }
         const float delta = wave_sum(dl);
-        float qv[64];
-        load_row64(q_rows + (int64_t)i * D + h * 64, qv);
-        for (int j = lane; j < S; j += 64) {
-            const float p = j < nkeys ? pr[j] : 0.f;
-            const float ds = j < nkeys ? p * (sc[j] - delta) * 0.125f : 0.f;
-            bf16_t* dk = dqkv + base + j * ld;
+        // dK_j, dV_j rows (8 keys per wave store instruction, whole 128-byte rows), ds_j kept for the dq pass; dq accumulated
+        // on the way: lane holds its 8 dimensions of sum_{j = kl mod 8} ds_j K_j
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < S; j0 += 32) {
+            float kk[4][8], pv[4], dsv[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+                const bool live = j < nkeys;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kk[u][e] = 0.f;
+                if (live) load8(kbase + j * ld + piece, kk[u]);
+                pv[u] = live ? pr[j] : 0.f;
+                dsv[u] = live ? sc[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 8 + kl;
+                if (j >= S) continue;
+                const float p = pv[u];
+                const float ds = p * (dsv[u] - delta) * 0.125f;
                 bf16x8 tk, tv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    tk[e] = (bf16_t)(ds * qv[c * 8 + e]);
-                    tv[e] = (bf16_t)(p * dov[c * 8 + e]);
+                    tk[e] = (bf16_t)(ds * qv[e]);
+                    tv[e] = (bf16_t)(p * dov[e]);
                 }
-                *(bf16x8*)(dk + c * 8) = tk;
-                *(bf16x8*)(dk + D + c * 8) = tv;
+                bf16_t* dk = dqkv + base + j * ld + piece;
+                *(bf16x8*)dk = tk;
+                *(bf16x8*)(dk + D) = tv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(ds, kk[u][e], acc[e]);
             }
-            sc[j] = ds;
         }
-    }
-    __syncthreads();
-    if (active) {
-        const bf16_t* kp = kbase + lane;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int j = 0;
-        for (; j + 4 <= nkeys; j += 4) {
-            a0 = __builtin_fmaf(sc[j], (float)kp[j * ld], a0);
-            a1 = __builtin_fmaf(sc[j + 1], (float)kp[(j + 1) * ld], a1);
-            a2 = __builtin_fmaf(sc[j + 2], (float)kp[(j + 2) * ld], a2);
-            a3 = __builtin_fmaf(sc[j + 3], (float)kp[(j + 3) * ld], a3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += __shfl_xor(acc[e], 8, 64);
+            acc[e] += __shfl_xor(acc[e], 16, 64);
+            acc[e] += __shfl_xor(acc[e], 32, 64);
         }
-        for (; j < nkeys; ++j) a0 = __builtin_fmaf(sc[j], (float)kp[j * ld], a0);
-        dq_rows[(int64_t)i * D + h * 64 + lane] = (bf16_t)((a0 + a1) + (a2 + a3));
+        if (kl == 0) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+            *(bf16x8*)(dq_rows + (int64_t)i * D + h * 64 + piece) = o;
+        }
     }
 }
 
