@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--full-last-block", action="store_true",
                     help="running.last_block_rows=False: evaluate the towers' last block on every token, as the reference does before "
                          "its read-out discards all rows but one (default: on the read-out rows only -- exact, see DESIGN.md)")
+    ap.add_argument("--no-full-last-block-check", action="store_true",
+                    help="skip the 8 extra steps that report the step time with the full last block beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
@@ -388,6 +390,21 @@ def main():
         nce_ms = e0.elapsed_time(e1) / 10
         out["infonce_alone"] = {"B": Bn, "E": E, "ms": round(nce_ms, 4), "tflops": round(6.0 * Bn * Bn * E / (nce_ms * 1e-3) / 1e12, 1),
                                 "note": "loss + dx1 + dx2 + dlogit_scale, B x B logits never stored"}
+        if world == 1 and lbr and not args.no_full_last_block_check:
+            # transparency: the same build, same box, with the towers' last block evaluated on EVERY token (what the reference
+            # computes before its read-out discards all rows but one) -- a short untimed-region extra, never `value`
+            for head in (mon.model.audio_head, mon.model.image_head):
+                if head is not None and hasattr(head, "encoder"):
+                    head.encoder.last_block_rows = False
+            for i in range(2):
+                one_step(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(6):
+                loss_full = one_step(2 + i)
+            torch.cuda.synchronize()
+            out["full_last_block"] = {"ms_per_step": round((time.perf_counter() - t1) / 6 * 1e3, 3), "steps": 6,
+                                      "note": "running.last_block_rows=False: the discarded rows of the last block computed too"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, T, Fq)
         print(json.dumps(out), flush=True)
