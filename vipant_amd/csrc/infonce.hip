@@ -7,9 +7,9 @@
 //           (B * #tiles floats instead of B^2) plus the diagonal;
 //   final   two small kernels merge the triples into row / column log-sum-exp, the loss and d logit_scale
 //           ( = sum dZ * Z, expressible from the triples );
-//   pass 2  recomputes the tiles that touch this rank's column strip, forms s * dZ = s * (softmax_row + softmax_col - 2 I) / B
-//           in registers and stores it as bf16 -- twice, the second launch with the two operands (and the two LSE vectors)
-//           swapped, which yields the same matrix TRANSPOSED without any transposing store;
+//   pass 2  recomputes the tiles that touch this rank's column or row strip, forms s * dZ = s * (softmax_row + softmax_col - 2 I) / B
+//           in registers once and stores it as bf16 in both orientations: from the accumulator layout, and TRANSPOSED through an
+//           LDS image of the tile (round 2 launched the kernel twice, the second time with the operands swapped);
 //   grads   dx2 = (s dZ)^T x1 and dx1 = (s dZ^T)^T x2 are then the same token-reduction (TN) contraction, split over all
 //           256 CUs (the row-major form of dx1, an NT contraction with 32 output tiles, left 7/8 of the chip idle).
 // Precision: inputs are fp32; pass 1 (the loss, the LSE vectors, d logit_scale) uses a hi/lo bf16 split of both operands
@@ -93,9 +93,13 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
     const int tile = xcd_remap(blockIdx.x, ntm * ntn);
     const int tm = tile / ntn, tn = tile % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
-    if (PASS == 2) {      // only the column strip of this launch's matrix feeds a gradient of this rank's rows
-        const bool cols_hit = n0 < row0 + nrows && n0 + BN > row0;
-        if (!cols_hit) return;
+    // pass 2: a tile feeds dx2 (through s dZ, rows m x columns n) when its COLUMNS meet this rank's strip, and dx1 (through the
+    // transpose, rows n x columns m) when its ROWS do
+    bool cols_hit = true, rows_hit = true;
+    if (PASS == 2) {
+        cols_hit = w.dz != nullptr && n0 < row0 + nrows && n0 + BN > row0;
+        rows_hit = w.dzt != nullptr && m0 < row0 + nrows && m0 + BM > row0;
+        if (!cols_hit && !rows_hit) return;
     }
     f32x4 acc[8][4];
     // K = 3E: [hi|hi|lo] . [hi|lo|hi]; pass 2: the first E columns only (hi . hi) -- its diagonal ELEMENTS, the only place where
@@ -175,29 +179,53 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
                 }
             }
     } else {
+        // s dZ of the tile, formed once; it leaves twice: straight from the accumulator layout (4 consecutive columns per lane)
+        // into dz, and -- through an LDS image [n][m] of the tile, 128 KiB, the operand stages are free by now -- as whole
+        // 512-byte rows of the TRANSPOSE into dzt.  16-byte chunks of an image row are XOR-swizzled with the row's quad index so
+        // that the four column quads a wave writes at once do not share banks.
         const float k = gscale / (float)B;
+        __syncthreads();                       // every wave is done reading the operand stages
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n4 = nb + j * 16;
-            if (n4 >= w.Bp) continue;
             f32x4 cl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) cl[r] = n4 + r < B ? w.clse[n4 + r] : 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = mb + i * 16;
-                if (m >= B) continue;
-                const float rl = w.rlse[m];
-                const float dg = tm == tn ? w.diag[m] : 0.f;
-                f32x4 d;
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < B && n4 < w.Bp) {
+                    const float rl = w.rlse[m];
+                    const float dg = tm == tn ? w.diag[m] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n4 + r;
-                    const float z = m == n ? dg : s * acc[i][j][r];
-                    const float g = (__expf(z - rl) + __expf(z - cl[r]) - (m == n ? 2.f : 0.f)) * k;
-                    d[r] = n < B ? g * s : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n4 + r;
+                        const float z = m == n ? dg : s * acc[i][j][r];
+                        const float g = (__expf(z - rl) + __expf(z - cl[r]) - (m == n ? 2.f : 0.f)) * k;
+                        d[r] = n < B ? g * s : 0.f;
+                    }
+                    if (cols_hit) *(bf16x4*)(w.dz + (int64_t)m * w.Bp + n4) = f32x4_to_bf16x4(d);
                 }
-                *(bf16x4*)(w.dz + (int64_t)m * w.Bp + n4) = f32x4_to_bf16x4(d);
+                if (rows_hit) {
+                    const int ml = wm * 128 + i * 16 + frow;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nl = wn * 64 + j * 16 + fq * 4 + r;
+                        *(bf16_t*)(smem + nl * 512 + ((((ml >> 3) ^ (((nl >> 2) & 3) << 1)) << 4) | ((ml & 7) << 1))) = (bf16_t)d[r];
+                    }
+                }
+            }
+        }
+        if (rows_hit) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int idx = t * 512 + (int)threadIdx.x;
+                const int nl = idx >> 5, ch = idx & 31;
+                const int n = n0 + nl, m8 = m0 + ch * 8;
+                if (n < B && m8 < w.Bp)
+                    *(u32x4*)(w.dzt + (int64_t)n * w.Bp + m8) = *(const u32x4*)(smem + nl * 512 + ((ch ^ (((nl >> 2) & 3) << 1)) << 4));
             }
         }
     }
@@ -324,20 +352,20 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     // rank's strip that does not (the reference's shipped default is 432 clips over 4 GPUs = 108 per rank) is widened to the left
     // by up to 7 columns, contracted into a scratch matrix, and its own rows copied out.
     const int64_t r0a = row0 & ~(int64_t)7, lead = row0 - r0a, nr = nrows + lead;
+    // one pass-2 launch writes s dZ (columns in the strip; feeds dx2) and its transpose (rows in the strip; feeds dx1)
+    NceWs t = w;
+    if (dx2 == nullptr) t.dz = nullptr;
+    if (dx1 == nullptr) t.dzt = nullptr;
+    hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)r0a, (int)nr, grad_scale);
+    VIPANT_LAUNCH_CHECK();
     if (dx2 != nullptr) {     // s dZ [m][n], columns n in the strip;  dx2[n, :] = sum_m s dZ[m][n] x1[m, :]
-        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, (int)r0a, (int)nr, grad_scale);
-        VIPANT_LAUNCH_CHECK();
         float* out = lead ? w.dxtmp : dx2;
         const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + r0a), w.Bp, (const uint16_t*)w.x1cat, 3 * E, out, E, B,
                                          nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
         if (lead) VIPANT_HIP_TRY(hipMemcpyAsync(dx2, out + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (dx1 != nullptr) {     // the same kernel on (x2, x1) with the LSE vectors swapped writes s dZ^T [n][m], columns m in the strip
-        NceWs t = w;
-        t.x1cat = w.x2cat; t.x2cat = w.x1cat; t.rlse = w.clse; t.clse = w.rlse; t.dz = w.dzt;
-        hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)r0a, (int)nr, grad_scale);
-        VIPANT_LAUNCH_CHECK();
+    if (dx1 != nullptr) {     // s dZ^T [n][m], columns m in the strip;  dx1[m, :] = sum_n s dZ^T[n][m] x2[n, :]
         float* out = lead ? w.dxtmp : dx1;
         const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dzt + r0a), w.Bp, (const uint16_t*)w.x2cat, 3 * E, out, E, B,
                                          nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
