@@ -66,6 +66,13 @@ int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_
                        int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Two contractions of one shape in one launch: C0 = A0^T . B0 and C1 = A1^T . B1 (the two feature gradients of the InfoNCE loss,
+ * cvap/module/decoder/loss_head.py:276-283: together they fill the chip with half the splits of two separate launches). */
+size_t vipant_gemm_tn_pair_workspace_bytes(int64_t M, int64_t P, int64_t Q);
+int32_t vipant_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, float* C0, const uint16_t* A1, const uint16_t* B1, float* C1,
+                            int64_t lda, int64_t ldb, int64_t ldc, int64_t M, int64_t P, int64_t Q, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Column sums over tokens (bias gradients): out[N] (+)= sum_m X[m, n]; X bf16 [M, N]. */
 size_t vipant_colsum_workspace_bytes(int64_t M, int64_t N);
 int32_t vipant_colsum_bf16(const uint16_t* X, int64_t ldx, float* out, int64_t M, int64_t N, int32_t accumulate,

@@ -355,6 +355,22 @@ def test_mha_spiky_scores(ops):
     assert_close(lse, rlse, 1e-4, 1e-3, "mha spiky lse")
 
 
+@pytest.mark.parametrize("M,P,Q", [(4096, 4096, 512), (1000, 520, 64), (129, 256, 512)])
+def test_gemm_tn_pair(ops, M, P, Q):
+    """Two token-reduction contractions of one shape in one launch (the InfoNCE feature gradients): each equals the single launch
+    of the same operands up to the split-K grouping, and the fp32 product."""
+    a0, a1 = rnd(M, P, seed=41, dtype=torch.bfloat16), rnd(M, P, seed=42, dtype=torch.bfloat16)
+    b0, b1 = rnd(M, Q, seed=43, dtype=torch.bfloat16), rnd(M, Q, seed=44, dtype=torch.bfloat16)
+    c0, c1 = torch.empty(P, Q, device=DEV), torch.empty(P, Q, device=DEV)
+    ws = torch.empty(ops.query("vipant_gemm_tn_pair_workspace_bytes", M, P, Q) + 256, dtype=torch.uint8, device=DEV)
+    ops.call("vipant_gemm_tn_pair", a0.data_ptr(), b0.data_ptr(), c0.data_ptr(), a1.data_ptr(), b1.data_ptr(), c1.data_ptr(), P, Q, Q,
+             M, P, Q, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    for a, b, c in ((a0, b0, c0), (a1, b1, c1)):
+        ref = a.float().t() @ b.float()
+        assert_close(c, ref, 1e-3, 2e-3 * float(ref.abs().max()), "tn pair")
+        assert_close(c, ops.gemm_tn(a, b, torch.empty(P, Q, device=DEV)), 1e-5, 1e-5 * float(ref.abs().max()), "tn pair vs single")
+
+
 @pytest.mark.parametrize("batch,S,H,causal,with_idx", [(3, 316, 12, False, False), (4, 77, 8, True, True), (2, 50, 12, False, True),
                                                        (5, 17, 2, True, False), (2, 645, 4, False, False)])
 def test_mha_rows(ops, batch, S, H, causal, with_idx):

@@ -215,8 +215,7 @@ constexpr int PP_B_BASE = 4 * PP_A_STAGE;                // [group][stage]
 constexpr int PP_B_SLOT = BK * TQ * 2;                   // 32 KiB
 constexpr int PP_LDS_BYTES = PP_B_BASE + 3 * PP_B_SLOT;  // 160 KiB
 
-__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTN p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tn_pp_body(const GemmTN& p, int block, char* smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTN p) {
 
     const int ntq = (p.Q + TQ - 1) / TQ, ntp = (p.P + TP - 1) / TP;
     const int ntiles = ntp * ntq;
-    const int bid = xcd_remap(blockIdx.x, ntiles * p.splits);
+    const int bid = xcd_remap(block, ntiles * p.splits);
     const int split = bid / ntiles, tile = bid % ntiles;
     const int tp = tile / ntq, tq = tile % ntq;
     const int p0 = tp * TP, q0 = tq * TQ;
@@ -402,8 +401,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTN p) {
     }
 }
 
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_kernel(GemmTN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_pp_body(p, (int)blockIdx.x, smem);
+}
+
+// two contractions of one shape in one launch (the two feature gradients of the InfoNCE loss: 2 x 32 tiles fill the chip with
+// half the splits, i.e. twice the K-tiles per workgroup and half the partial tiles to reduce)
+struct GemmTNPair { GemmTN a, b; int blocks_a; };
+__global__ __launch_bounds__(512, 2) void gemm_tn_pp_pair_kernel(GemmTNPair pr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool first = (int)blockIdx.x < pr.blocks_a;
+    tn_pp_body(first ? pr.a : pr.b, first ? (int)blockIdx.x : (int)blockIdx.x - pr.blocks_a, smem);
+}
+
+// blockIdx.y selects the problem of a pair (slab2 / C2: NULL for a single problem)
 __global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, int P, int Q, int splits,
-                                      int accumulate) {
+                                      int accumulate, const float* slab2 = nullptr, float* C2 = nullptr) {
+    if (blockIdx.y == 1) { slab = slab2; C = C2; }
     const int ntq = (Q + TQ - 1) / TQ, ntp = (P + TP - 1) / TP;
     const int ntiles = ntp * ntq;
     const int64_t total4 = (int64_t)ntiles * TP * TQ / 4;
@@ -442,6 +457,16 @@ __global__ __launch_bounds__(256) void gemm_tn_colsum_reduce_kernel(const float*
         const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         out[i] = accumulate ? out[i] + s : s;
     }
+}
+
+void plan_tiles(int64_t M, int64_t tiles, int* splits, int* kt_per_split) {
+    const int64_t nk = ceil_div(M, BK);
+    int64_t s = 256 / tiles;
+    if (s < 1) s = 1;
+    if (s > nk) s = nk;
+    const int64_t per = ceil_div(nk, s);
+    *splits = (int)ceil_div(nk, per);
+    *kt_per_split = (int)per;
 }
 
 void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
@@ -513,6 +538,57 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     if (a_colsum != nullptr) {
         hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 64)), dim3(256), 0, s,
                            (const float*)cs_part, a_colsum, (int)P, (int)(ceil_div(P, TP) * TP), (int)(splits * ceil_div(Q, TQ)), accumulate);
+        VIPANT_LAUNCH_CHECK();
+    }
+    return VIPANT_OK;
+}
+
+// Two contractions of the same shape in one launch: C0 = A0^T . B0, C1 = A1^T . B1 (no accumulate, no column sums).
+extern "C" size_t vipant_gemm_tn_pair_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
+    const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
+    int splits, per;
+    plan_tiles(M, 2 * tiles, &splits, &per);
+    return 2 * (size_t)splits * (size_t)tiles * TP * TQ * sizeof(float);
+}
+
+extern "C" int32_t vipant_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, float* C0, const uint16_t* A1, const uint16_t* B1,
+                                       float* C1, int64_t lda, int64_t ldb, int64_t ldc, int64_t M, int64_t P, int64_t Q,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(M > 0 && P > 0 && Q > 0 && Q % 4 == 0, VIPANT_EBADSHAPE, "gemm_tn_pair: bad shape");
+    VIPANT_REQUIRE(lda >= P && ldb >= Q && ldc >= Q && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, VIPANT_EALIGN,
+                   "gemm_tn_pair: bad leading dims");
+    VIPANT_REQUIRE(((uintptr_t)A0 % 16 == 0) && ((uintptr_t)B0 % 16 == 0) && ((uintptr_t)C0 % 16 == 0) && ((uintptr_t)A1 % 16 == 0) &&
+                       ((uintptr_t)B1 % 16 == 0) && ((uintptr_t)C1 % 16 == 0), VIPANT_EALIGN, "gemm_tn_pair: operands must be 16-byte aligned");
+    const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
+    int splits, per;
+    plan_tiles(M, 2 * tiles, &splits, &per);
+    VIPANT_REQUIRE((int64_t)(per + 3) * BK * (lda > ldb ? lda : ldb) * 2 < (1ll << 32), VIPANT_EBADSHAPE,
+                   "gemm_tn_pair: per-split byte range exceeds 4 GiB");
+    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_gemm_tn_pair_workspace_bytes(M, P, Q), VIPANT_ENOWORKSPACE,
+                   "gemm_tn_pair: workspace too small");
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        configured = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int direct = splits == 1 ? 1 : 0;
+    float* slab0 = (float*)workspace;
+    float* slab1 = slab0 + (size_t)splits * (size_t)tiles * TP * TQ;
+    GemmTNPair pr;
+    pr.a = GemmTN{(const bf16_t*)A0, (const bf16_t*)B0, direct ? C0 : slab0, lda, ldb, direct ? ldc : TQ, (int)M, (int)P, (int)Q, splits, per,
+                  direct, nullptr};
+    pr.b = GemmTN{(const bf16_t*)A1, (const bf16_t*)B1, direct ? C1 : slab1, lda, ldb, direct ? ldc : TQ, (int)M, (int)P, (int)Q, splits, per,
+                  direct, nullptr};
+    pr.blocks_a = (int)(tiles * splits);
+    hipLaunchKernelGGL(gemm_tn_pp_pair_kernel, dim3((unsigned)(2 * tiles * splits)), dim3(512), PP_LDS_BYTES, s, pr);
+    VIPANT_LAUNCH_CHECK();
+    if (!direct) {
+        const int64_t total4 = tiles * TP * TQ / 4;
+        int blocks = (int)ceil_div(total4, 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks, 2), dim3(256), 0, s, (const float*)slab0, C0, ldc, (int)P, (int)Q, splits, 0,
+                           (const float*)slab1, C1);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;

@@ -25,7 +25,7 @@ using namespace ntcore;
 
 struct NceWs {       // carved out of the caller's workspace; all offsets 256-B aligned
     bf16_t *x1cat, *x2cat, *dz, *dzt;
-    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part, *dxtmp;   // scal[0] = s, scal[1] = clamped
+    float *rmax, *rsum, *rwz, *cmax, *csum, *cwz, *diag, *rlse, *clse, *scal, *part, *dxtmp, *dxtmp2;   // scal[0] = s, scal[1] = clamped
     void* tn_ws;
     size_t tn_bytes, total;
     int Bp, rparts, cparts;
@@ -52,7 +52,10 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     w.scal = (float*)take(256);
     w.part = (float*)take((size_t)ceil_div(B, 16) * 2 * 4);
     w.dxtmp = (float*)take((size_t)(B + 8) * E * 4);          // gradient rows of a strip that does not start on a multiple of 8
+    w.dxtmp2 = (float*)take((size_t)(B + 8) * E * 4);
     w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
+    const size_t pair_bytes = vipant_gemm_tn_pair_workspace_bytes(B, B, E);
+    if (pair_bytes > w.tn_bytes) w.tn_bytes = pair_bytes;
     w.tn_ws = take(w.tn_bytes);
     w.total = off;
     return w;
@@ -358,14 +361,28 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     if (dx1 == nullptr) t.dzt = nullptr;
     hipLaunchKernelGGL(nce_tile_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, s, t, (int)B, K, (int)r0a, (int)nr, grad_scale);
     VIPANT_LAUNCH_CHECK();
-    if (dx2 != nullptr) {     // s dZ [m][n], columns n in the strip;  dx2[n, :] = sum_m s dZ[m][n] x1[m, :]
+    // dx2[n, :] = sum_m s dZ[m][n] x1[m, :] (columns n in the strip) and dx1[m, :] = sum_n s dZ^T[n][m] x2[n, :] (columns m in the
+    // strip): the same token-reduction contraction twice -- one launch for both when both are wanted
+    if (dx1 != nullptr && dx2 != nullptr) {
+        float* out2 = lead ? w.dxtmp : dx2;
+        float* out1 = lead ? w.dxtmp2 : dx1;
+        const int32_t e = vipant_gemm_tn_pair((const uint16_t*)(w.dz + r0a), (const uint16_t*)w.x1cat, out2, (const uint16_t*)(w.dzt + r0a),
+                                              (const uint16_t*)w.x2cat, out1, w.Bp, 3 * E, E, B, nr, E, w.tn_ws, w.tn_bytes, stream);
+        if (e != VIPANT_OK) return e;
+        if (lead) {
+            VIPANT_HIP_TRY(hipMemcpyAsync(dx2, out2 + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+            VIPANT_HIP_TRY(hipMemcpyAsync(dx1, out1 + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        return VIPANT_OK;
+    }
+    if (dx2 != nullptr) {
         float* out = lead ? w.dxtmp : dx2;
         const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dz + r0a), w.Bp, (const uint16_t*)w.x1cat, 3 * E, out, E, B,
                                          nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
         if (e != VIPANT_OK) return e;
         if (lead) VIPANT_HIP_TRY(hipMemcpyAsync(dx2, out + lead * E, (size_t)nrows * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (dx1 != nullptr) {     // s dZ^T [n][m], columns m in the strip;  dx1[m, :] = sum_n s dZ^T[n][m] x2[n, :]
+    if (dx1 != nullptr) {
         float* out = lead ? w.dxtmp : dx1;
         const int32_t e = vipant_gemm_tn((const uint16_t*)(w.dzt + r0a), w.Bp, (const uint16_t*)w.x2cat, 3 * E, out, E, B,
                                          nr, E, 0, nullptr, w.tn_ws, w.tn_bytes, stream);
