@@ -118,6 +118,13 @@ int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t*
                        float* delta, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H, int32_t causal,
                        void* stream);
 
+/* The patch embedding written straight into the token matrix (ViTPreEncoder, cvap/module/val.py:249-257): for m = item * P + patch,
+ * tokens[item * (P + 1) + patch + 1, :] = A[m, :] . B^T + pos[patch + 1, :] (fp32, ldc = N); the class-token rows
+ * tokens[item * S, :] = cls + pos[0, :] are vipant_tokens_cls_rows'. */
+int32_t vipant_gemm_nt_tokens(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* tokens, const float* pos,
+                              int64_t b, int64_t P, int64_t N, int64_t K, void* stream);
+int32_t vipant_tokens_cls_rows(const float* cls, const float* pos, float* tokens, int64_t b, int64_t S, int64_t D, void* stream);
+
 /* ---- the same attention for ONE query per (item, head): the last block of a tower on its read-out rows ----------
  * Both read-outs take one token per item from the stack's output (the class token, cvap/module/val.py:288-289; the
  * end-of-text token, val.py:143-145), so only that row of the last block's output is ever read and only it carries a
@@ -351,7 +358,7 @@ int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const uint16_t* w_p
 
 /* K1 -- ViTPreEncoder.forward (cvap/module/val.py:228-259): patch conv as im2col + contraction, cls token, positional table,
  * ln_pre.  x fp32 [b,C,T,F]; conv_w fp32 [Dw,Cw,ph,pw] (mean_channels != 0: the Cw stored channels are averaged, val.py:236-244);
- * scratch / saved: w_eff bf16 [Dw,kcols], patches bf16 [b*P,kcols], pe fp32 [b*P,Dw], tokens fp32 [b*S,Dw] (kcols =
+ * scratch / saved: w_eff bf16 [Dw,kcols], patches bf16 [b*P,kcols], pe: unused since round 3 (may be NULL), tokens fp32 [b*S,Dw] (kcols =
  * (mean_channels ? 1 : Cw)*ph*pw, P = nrow*ncol, S = P+1); out fp32 [b*S,Dw] = the residual stream; mean / rstd fp32 [b*S]. */
 int32_t vipant_patch_embed_ln_fwd(const float* x, const float* conv_w, const float* cls, const float* pos, const float* gamma,
                                   const float* beta, uint16_t* w_eff, uint16_t* patches, float* pe, float* tokens, float* out,

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "vipant_gemm_nt": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _i64, _i64, _i64, _i32, _p]),
     "vipant_gemm_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vipant_gemm_tn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "vipant_gemm_nt_tokens": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p]),
+    "vipant_tokens_cls_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_gemm_tn_pair_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vipant_gemm_tn_pair": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_colsum_workspace_bytes": (_sz, [_i64, _i64]),

@@ -229,8 +229,10 @@ extern "C" int32_t vipant_patch_embed_ln_fwd(const float* x, const float* conv_w
     VIPANT_REQUIRE(nrow > 0 && ncol > 0 && kcols % 64 == 0, VIPANT_EBADSHAPE, "patch_embed_ln_fwd: bad geometry");
     TRY(vipant_conv_weight_prep(conv_w, w_eff, Dw, Cw, ph * pw, mean_channels, stream));
     TRY(vipant_im2col(x, patches, b, C, T, F, ph, pw, sh, sw, stream));
-    TRY(vipant_gemm_nt(patches, kcols, w_eff, kcols, pe, Dw, nullptr, nullptr, 1.0f, b * P, Dw, kcols, VIPANT_EPI_F32, stream));
-    TRY(vipant_assemble_tokens(pe, cls, pos, tokens, b, P, Dw, stream));
+    // the contraction writes the patch rows of the token matrix itself (+ pos); `pe` is no longer used (kept in the signature)
+    (void)pe;
+    TRY(vipant_gemm_nt_tokens(patches, kcols, w_eff, kcols, tokens, pos, b, P, Dw, kcols, stream));
+    TRY(vipant_tokens_cls_rows(cls, pos, tokens, b, S, Dw, stream));
     return vipant_layernorm_fwd(tokens, Dw, gamma, beta, nullptr, out, mean, rstd, b * S, Dw, nullptr, nullptr, stream);
 }
 

@@ -192,6 +192,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
     }
 }
 
+// tokens[item * S, :] = cls + pos[0, :]: the class-token rows (the patch rows come from vipant_gemm_nt_tokens)
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                       float* __restrict__ tokens, int64_t b, int64_t S, int D) {
+    const int d4 = D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < b * d4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % d4) * 4;
+        *(f32x4*)(tokens + (i / d4) * S * D + c) = *(const f32x4*)(cls + c) + *(const f32x4*)(pos + c);
+    }
+}
+
 // dpatches (bf16) = dtokens rows s >= 1; dpos[s] = sum_b dtokens[b, s]; dcls = dpos row 0 (before accumulate).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dtok, bf16_t* __restrict__ dpatches,
                                                            float* dcls, float* dpos, int accumulate, int64_t b, int P,
@@ -519,6 +529,14 @@ extern "C" int32_t vipant_assemble_tokens(const float* patches, const float* cls
     VIPANT_REQUIRE(b > 0 && P > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "assemble_tokens: bad shape");
     hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(b * (P + 1) * D / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        patches, cls, pos, tokens, b, (int)P, (int)D);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_tokens_cls_rows(const float* cls, const float* pos, float* tokens, int64_t b, int64_t S, int64_t D,
+                                          void* stream) {
+    VIPANT_REQUIRE(b > 0 && S > 0 && D % 4 == 0, VIPANT_EBADSHAPE, "tokens_cls_rows: bad shape");
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for(b * D / 4, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos, tokens, b, S, (int)D);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

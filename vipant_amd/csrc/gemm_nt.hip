@@ -23,6 +23,10 @@ struct GemmNT {
     float alpha;
     int dbg;   // VIPANT_GEMM_VARIANT (timing experiments only): bit 0 = skip the epilogue stores
     const uint8_t* sa; const uint8_t* sb;    // fp8 operands only: per-row E8M0 exponents of A and B (value = e4m3 * 2^(byte - 127))
+    // token assembly (EPI_F32 of the plain kernel only; ViTPreEncoder, cvap/module/val.py:249-257): with tok_p > 0, row m = (item,
+    // patch) of the product lands in row item * (tok_p + 1) + patch + 1 of C and gets pos[patch + 1, :] added -- the patch
+    // embedding written straight into the token matrix, whose class-token rows a one-row-per-item kernel fills
+    int tok_p; const float* pos;
 };
 
 template <int EPI>
@@ -55,8 +59,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(GemmNT p) {
         for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm * 128 + i * 16 + frow;
             if (m >= p.M) continue;
-            const int64_t o = (int64_t)m * p.ldc + n4;
+            int64_t o = (int64_t)m * p.ldc + n4;
             f32x4 v = acc[i][j] + bv;
+            if (EPI == VIPANT_EPI_F32 && p.tok_p > 0) {
+                const int item = m / p.tok_p, patch = m - item * p.tok_p;
+                o = ((int64_t)item * (p.tok_p + 1) + patch + 1) * p.ldc + n4;
+                v += *(const f32x4*)(p.pos + (int64_t)(patch + 1) * p.N + n4);
+            }
             if (EPI == VIPANT_EPI_BF16) {
                 *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(v);
             } else if (EPI == VIPANT_EPI_F32) {
@@ -903,7 +912,7 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
     VIPANT_REQUIRE(256 * lda * 2 < (1ll << 31) && 256 * ldb * 2 < (1ll << 31), VIPANT_EBADSHAPE,
                    "gemm_nt: leading dimension too large");
     static const int dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
-    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg, nullptr, nullptr};
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg, nullptr, nullptr, 0, nullptr};
     hipStream_t s = (hipStream_t)stream;
     const bool staged = (N % 8 == 0) && (ldc % 8 == 0) && !(dbg & 2);
     const bool pp = staged && K >= 128 && !(dbg & 16);
@@ -937,6 +946,22 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
     }
 }
 
+// The patch embedding written straight into the token matrix: tokens[item * (P + 1) + patch + 1, :] = A[item * P + patch, :] . B^T +
+// pos[patch + 1, :], fp32 (the class-token rows are vipant_tokens_cls_rows').  Replaces an fp32 [b P, N] intermediate and the pass
+// that re-read it (assemble_tokens): 0.22 ms of the step at cfg2.
+extern "C" int32_t vipant_gemm_nt_tokens(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* tokens,
+                                         const float* pos, int64_t b, int64_t P, int64_t N, int64_t K, void* stream) {
+    VIPANT_REQUIRE(b > 0 && P > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0 && b * P < (1ll << 31), VIPANT_EBADSHAPE,
+                   "gemm_nt_tokens: bad shape b=%ld P=%ld N=%ld K=%ld", (long)b, (long)P, (long)N, (long)K);
+    VIPANT_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && 256 * lda * 2 < (1ll << 31) && 256 * ldb * 2 < (1ll << 31),
+                   VIPANT_EALIGN, "gemm_nt_tokens: bad leading dims");
+    VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)tokens % 16 == 0) && ((uintptr_t)pos % 16 == 0),
+                   VIPANT_EALIGN, "gemm_nt_tokens: operands must be 16-byte aligned");
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, tokens, nullptr, nullptr, lda, ldb, N, (int)(b * P), (int)N, (int)K, 1.0f, 0, nullptr,
+             nullptr, (int)P, pos};
+    return launch<VIPANT_EPI_F32>(p, (hipStream_t)stream);
+}
+
 // e4m3 x e4m3 -> bf16: C = (A * 2^(sa - 127)) (B * 2^(sb - 127))^T [+ bias], the ping-pong kernel at ES = 1.
 extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb,
                                        const uint8_t* sb, void* C, int64_t ldc, const float* bias, void* aux, int64_t M, int64_t N,
@@ -951,7 +976,7 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
     VIPANT_REQUIRE(sa != nullptr && sb != nullptr, VIPANT_EBADSHAPE, "gemm_nt_e4m3: the row scales of both operands are required");
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
     static const int fp8_dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
-    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, sa, sb};
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, sa, sb, 0, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case VIPANT_EPI_BF16:

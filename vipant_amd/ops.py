@@ -380,14 +380,13 @@ class PatchEmbedFn(torch.autograd.Function):
         dev = x.device
         w_eff = torch.empty((D, kcols), dtype=BF16, device=dev)
         patches = torch.empty((b * P, kcols), dtype=BF16, device=dev)
-        pe = torch.empty((b * P, D), dtype=F32, device=dev)
         tok = torch.empty((b * S, D), dtype=F32, device=dev)
         out = torch.empty((b * S, D), dtype=F32, device=dev)
         mean = torch.empty((b * S,), dtype=F32, device=dev)
         rstd = torch.empty((b * S,), dtype=F32, device=dev)
         call("vipant_patch_embed_ln_fwd", x.data_ptr(), conv_w.detach().contiguous().data_ptr(),
              cls.detach().contiguous().data_ptr(), pos.detach().contiguous().data_ptr(), ln_w.detach().data_ptr(),
-             ln_b.detach().data_ptr(), w_eff.data_ptr(), patches.data_ptr(), pe.data_ptr(), tok.data_ptr(), out.data_ptr(),
+             ln_b.detach().data_ptr(), w_eff.data_ptr(), patches.data_ptr(), None, tok.data_ptr(), out.data_ptr(),
              mean.data_ptr(), rstd.data_ptr(), b, Cx, T, Fq, D, Cw, ph, pw, sh, sw, int(mean_ch), _stream())
         ctx.save_for_backward(patches, tok, mean, rstd, ln_w)
         ctx.meta = (b, P, D, Cw, ph * pw, mean_ch, tuple(conv_w.shape), tuple(pos.shape))
