@@ -415,15 +415,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_pair_kernel(GemmTNPair pr) 
     tn_pp_body(first ? pr.a : pr.b, first ? (int)blockIdx.x : (int)blockIdx.x - pr.blocks_a, smem);
 }
 
-// blockIdx.y selects the problem of a pair (slab2 / C2: NULL for a single problem)
-__global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, int P, int Q, int splits,
-                                      int accumulate, const float* slab2 = nullptr, float* C2 = nullptr) {
-    if (blockIdx.y == 1) { slab = slab2; C = C2; }
+__device__ __forceinline__ void tn_reduce_blocks(const float* slab, float* C, int64_t ldc, int P, int Q, int splits, int accumulate,
+                                                 int block, int nblocks) {
     const int ntq = (Q + TQ - 1) / TQ, ntp = (P + TP - 1) / TP;
     const int ntiles = ntp * ntq;
     const int64_t total4 = (int64_t)ntiles * TP * TQ / 4;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)block * blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)nblocks * blockDim.x) {
         const int64_t e = idx * 4;
         const int tile = (int)(e / (TP * TQ));
         const int r = (int)(e % (TP * TQ)) / TQ, c = (int)(e % TQ);
@@ -437,14 +434,21 @@ __global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, 
     }
 }
 
+// blockIdx.y selects the problem of a pair (slab2 / C2: NULL for a single problem)
+__global__ void gemm_tn_reduce_kernel(const float* slab, float* C, int64_t ldc, int P, int Q, int splits,
+                                      int accumulate, const float* slab2 = nullptr, float* C2 = nullptr) {
+    if (blockIdx.y == 1) { slab = slab2; C = C2; }
+    tn_reduce_blocks(slab, C, ldc, P, Q, splits, accumulate, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // out[i] (+)= sum over the `parts` partial vectors.  64 columns per 256-thread block, 4 threads per column each taking every
 // fourth partial with independent loads in flight (a single thread walking 20-80 partials one after the other made this tiny
 // kernel 20-90 us long).
-__global__ __launch_bounds__(256) void gemm_tn_colsum_reduce_kernel(const float* part, float* out, int P, int stride, int parts,
-                                                                    int accumulate) {
+__device__ __forceinline__ void colsum_reduce_block(const float* part, float* out, int P, int stride, int parts, int accumulate,
+                                                    int block) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + c;
+    const int i = block * 64 + c;
     float s0 = 0.f, s1 = 0.f;
     if (i < P) {
         int k = sub;
@@ -457,6 +461,20 @@ __global__ __launch_bounds__(256) void gemm_tn_colsum_reduce_kernel(const float*
         const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         out[i] = accumulate ? out[i] + s : s;
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_colsum_reduce_kernel(const float* part, float* out, int P, int stride, int parts,
+                                                                    int accumulate) {
+    colsum_reduce_block(part, out, P, stride, parts, accumulate, (int)blockIdx.x);
+}
+
+// the split reduction of C and the column-sum reduction of the same launch as ONE launch: blocks [0, nred) reduce C, the rest
+// take 64 columns of the column sums each
+__global__ __launch_bounds__(256) void gemm_tn_reduce_both_kernel(const float* slab, float* C, int64_t ldc, int P, int Q, int splits,
+                                                                  int accumulate, int nred, const float* cs_part, float* cs_out,
+                                                                  int cs_stride, int cs_parts) {
+    if ((int)blockIdx.x < nred) tn_reduce_blocks(slab, C, ldc, P, Q, splits, accumulate, (int)blockIdx.x, nred);
+    else colsum_reduce_block(cs_part, cs_out, P, cs_stride, cs_parts, accumulate, (int)blockIdx.x - nred);
 }
 
 void plan_tiles(int64_t M, int64_t tiles, int* splits, int* kt_per_split) {
@@ -527,17 +545,25 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     if (variant & 16) hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 2 * STAGE_BYTES, s, p);
     else hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(512), PP_LDS_BYTES, s, p);
     VIPANT_LAUNCH_CHECK();
+    const int cs_parts = (int)(splits * ceil_div(Q, TQ)), cs_stride = (int)(ceil_div(P, TP) * TP);
     if (!direct) {
         const int64_t total4 = tiles * TP * TQ / 4;
         int blocks = (int)ceil_div(total4, 256);
         if (blocks > 2048) blocks = 2048;
+        if (a_colsum != nullptr) {       // one launch for both reductions
+            hipLaunchKernelGGL(gemm_tn_reduce_both_kernel, dim3((unsigned)(blocks + ceil_div(P, 64))), dim3(256), 0, s,
+                               (const float*)workspace, C, ldc, (int)P, (int)Q, splits, accumulate, blocks, (const float*)cs_part, a_colsum,
+                               cs_stride, cs_parts);
+            VIPANT_LAUNCH_CHECK();
+            return VIPANT_OK;
+        }
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, C, ldc,
                            (int)P, (int)Q, splits, accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     if (a_colsum != nullptr) {
         hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 64)), dim3(256), 0, s,
-                           (const float*)cs_part, a_colsum, (int)P, (int)(ceil_div(P, TP) * TP), (int)(splits * ceil_div(Q, TQ)), accumulate);
+                           (const float*)cs_part, a_colsum, (int)P, cs_stride, cs_parts, accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;
