@@ -6,6 +6,8 @@ gradients in the 512-clip batch must equal, bit for bit, what the same sample gi
 are pinned to the reference by tests/test_model_gpu.py).
 """
 import math
+import os
+import sys
 from types import SimpleNamespace as NS
 
 import pytest
@@ -157,6 +159,40 @@ def test_full_size_step_starts_at_two_ln_batch():
     assert abs(losses[0] - loss_oracle) < 1e-4, (losses[0], loss_oracle)
     assert abs(losses[0] - 2 * math.log(B)) < 0.5, losses            # and it starts near the uniform-softmax value
     assert losses[-1] < losses[0], losses
+
+
+def test_full_size_last_block_rows_match_full_block():
+    """The benchmarked shape (audio ViT-B, 12 blocks, 1024 x 128 spectrograms -> S = 316, 512 clips) with the weights of the
+    `e2e_cfg2` fixture: loss + backward with the last block on its read-out rows (`running.last_block_rows`, the default) against
+    the same with the full last block -- features, loss and the gradient of every parameter.  (From-scratch weights would not do:
+    their features are nearly identical across clips and the contrastive gradient is rounding noise in either mode.)"""
+    import vipant_amd.module as M
+    from vipant_amd import ops
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_model_gpu import audio_cfg
+    runs = []
+    aud = gen.det_randn("full/rows/aud", (B, 1, 1024, 128)).to(DEV)
+    img = ops.l2_normalize(gen.det_randn("full/rows/img", (B, 512)).to(DEV))
+    for rows in (False, True):
+        head = M.build_audio_head(audio_cfg(1024, 128, 12))
+        assert head.misc.positional_embedding.shape[0] == S
+        head.load_state_dict(gen.det_weights("e2e/cfg2", gen.vit_head_shapes(768, 12, 512, S)), strict=True)
+        lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
+        head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
+        head.encoder.last_block_rows = rows
+        feat = head(aud, normalized=True)
+        loss = lhead(img, feat, None, normalized=True)
+        loss.backward()
+        runs.append((feat.detach().clone(), float(loss), {k: p.grad.double() for k, p in head.named_parameters()}))
+        del head, lhead, feat, loss
+        torch.cuda.empty_cache()
+    (f0, l0, g0), (f1, l1, g1) = runs
+    diffs = sorted(((float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)), k) for k in g0), reverse=True)
+    print(f"full size, read-out rows vs full last block: feature max rel diff {max_rel(f1, f0):.2e}, loss {l0:.5f} / {l1:.5f}, "
+          f"worst gradient rel-L2 diff {diffs[0][0]:.3e} ({diffs[0][1]}), median {diffs[len(diffs) // 2][0]:.3e}")
+    assert max_rel(f1, f0) < 1e-2, max_rel(f1, f0)
+    assert abs(l1 - l0) < 1e-3, (l0, l1)
+    assert diffs[0][0] < 5e-2, diffs[0]
 
 
 def test_vit_l_depth_sample_independence(ops):
