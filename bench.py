@@ -403,7 +403,8 @@ def main():
             for i in range(6):
                 loss_full = one_step(2 + i)
             torch.cuda.synchronize()
-            out["full_last_block"] = {"ms_per_step": round((time.perf_counter() - t1) / 6 * 1e3, 3), "steps": 6,
+            ms_full = (time.perf_counter() - t1) / 6 * 1e3
+            out["full_last_block"] = {"ms_per_step": round(ms_full, 3), "value": round(b * world / (ms_full * 1e-3), 2), "unit": "pairs/s", "steps": 6,
                                       "note": "running.last_block_rows=False: the discarded rows of the last block computed too"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, T, Fq)
