@@ -344,11 +344,16 @@ def test_mha(ops, batch, S, H, causal):
     assert_close(dqkv, qr.grad, 2e-2, 2e-2 * scale, "mha bwd")
 
 
-def test_mha_spiky_scores(ops):
-    """A dominant key per query (exact-softmax path must not lose it to rounding / masking)."""
+@pytest.mark.parametrize("key,gain", [(7, 40), (200, 40), (200, 250), (7, 250), (315, 250), (170, 120)])
+def test_mha_spiky_scores(ops, key, gain):
+    """A dominant key per query (exact-softmax path must not lose it to rounding / masking).  The wide forward (csrc/attention_wide.hip)
+    takes a whole query block's keys in two halves and exponentiates the second half against the FIRST half's maximum unless that would
+    overflow: keys in either half, with a lead small enough for the common path (gain 40: 18 in the exponent) and large enough to
+    force the rescale branch (gain 250: > 64), on the whole blocks (query 100) and on the block two waves share (query 300)."""
     batch, S, H = 1, 316, 1
     qkv = rnd(S, 192, seed=3, dtype=torch.bfloat16, scale=0.2)
-    qkv[:, 64:128][7] = qkv[:, :64][100] * 40      # key 7 aligned with query 100
+    qkv[:, 64:128][key] = qkv[:, :64][100] * gain       # key aligned with query 100
+    qkv[:, :64][300] = qkv[:, :64][100]                 # ... and with query 300 (last query block)
     out, lse = ops.mha_fwd(qkv, batch, S, H, False)
     ref, rlse = ref_attention(qkv, batch, S, H, False)
     assert_close(out, ref, 1e-2, 1e-2, "mha spiky")

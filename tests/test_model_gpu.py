@@ -609,14 +609,19 @@ def test_e4m3_step_under_the_activation_memory_plans():
         assert err <= 1e-6 + 1e-4 * float(p1[k].abs().max()), (k, err)
 
 
+@pytest.mark.parametrize("rows", [True, False], ids=["rows", "fullblock"])
+@pytest.mark.parametrize("stream", ["fp16", "fp32"])
 @pytest.mark.parametrize("tag", ["va", "at"])
-def test_trainer_trajectory_golden(M, golden, tag):
+def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
     """Four optimisation steps of the product path -- heads, loss head, fused LARS, `adjust_learning_rate` -- against the
     trajectory the REFERENCE's own pieces produced on the same weights and batches (tests/golden/make_golden.py, section viii):
-    learning rates exactly, every step's loss, every tunable tensor's update norm, and the final small tensors."""
+    learning rates exactly, every step's loss, every tunable tensor's update norm, and the final small tensors.  All four corners
+    of the two round-3 defaults (`running.stream_dtype`, `running.last_block_rows`), so that a loss-error change can be attributed."""
     g = golden(f"traj_{tag}")
     L, b, T, Fq = 2, 8, 256, 64
     head = M.build_audio_head(audio_cfg(T, Fq, L))
+    head.encoder.stream_f16 = stream == "fp16"
+    head.encoder.last_block_rows = rows
     S = head.misc.positional_embedding.shape[0]
     w0 = gen.det_weights(f"traj/{tag}", gen.vit_head_shapes(768, L, 512, S))
     head.load_state_dict(w0, strict=True)
@@ -660,7 +665,7 @@ def test_trainer_trajectory_golden(M, golden, tag):
                 assert dn == 0.0, (step, named[i][0])
             else:
                 worst_norm = max(worst_norm, abs(dn / ref - 1))
-    observe(f"traj_{tag}", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
+    observe(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
     assert worst_loss < 5e-3, worst_loss                  # b = 8: the bf16 towers' loss error at this batch size (observed ~2e-3)
     assert worst_norm < 6e-2, worst_norm                  # update norms: LARS trust ratio x gradient norm, bf16 gradient noise
     for k, p in named:

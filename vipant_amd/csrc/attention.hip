@@ -18,24 +18,15 @@
 // no float atomics, bitwise reproducible.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attn_common.h"
+
+using namespace vipant_attn;
 
 namespace {
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float SCALE = 0.125f;              // 1/sqrt(64)
-constexpr float C2 = SCALE * LOG2E;
 
 __device__ __forceinline__ int img_swz(int r) { return ((r >> 1) & 3) << 1; }
 
 // Fill a [rows8*8 x 64] bf16 LDS image from `rows8*8` consecutive rows (stride ld_bytes) of a buffer.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
-    // descriptor inputs made provably wave-uniform, otherwise hipcc wraps every buffer op in a waterfall loop
-    const uint64_t a = (uint64_t)base;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return make_rsrc((const void*)(((uint64_t)hi << 32) | lo), (uint32_t)__builtin_amdgcn_readfirstlane(bytes));
-}
-
 __device__ __forceinline__ void dma_image(char* lds, __amdgpu_buffer_rsrc_t rs, uint32_t ld_bytes, int rows8,
                                           int wave, int nwaves, int lane) {
     for (int blk = wave; blk < rows8; blk += nwaves) {
@@ -113,12 +104,6 @@ __device__ __forceinline__ void settle(bf16x8& f) { lds_raw_use(f); }
 
 template <int V> struct Int2 { static constexpr int value = V; };
 
-struct MhaArgs {
-    const bf16_t* qkv; bf16_t* out; float* lse;
-    const bf16_t* dout; float* delta; bf16_t* dqkv;
-    int batch, S, H;
-    int stagger;
-};
 
 // ------------------------------------------------------------------------------------------- forward
 template <int NT, bool CAUSAL, int NW, int EDGE>
@@ -1148,6 +1133,12 @@ int32_t launch_stream(const MhaArgs& a, hipStream_t s) {
     return VIPANT_OK;
 }
 
+// VIPANT_ATTN_BWD=2: the two-pass backward (round 2) for A/B timing; VIPANT_ATTN_STAGGER: see mha_bwd1_kernel
+int attn_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 int attn_waves() {
     static const int nw = getenv("VIPANT_ATTN_WAVES") ? atoi(getenv("VIPANT_ATTN_WAVES")) : 8;
     return nw == 4 ? 4 : 8;
@@ -1199,11 +1190,6 @@ int32_t launch_bwd1(const MhaArgs& a, hipStream_t s) {
     return VIPANT_OK;
 }
 
-// VIPANT_ATTN_BWD=2: the two-pass backward (round 2) for A/B timing; VIPANT_ATTN_STAGGER: see mha_bwd1_kernel
-int attn_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 // EDGE = 2 when only the last two key tiles can be partial (S > (NT - 2) * 16), else every tile carries mask code.
 template <int NT, bool CAUSAL>
@@ -1211,6 +1197,12 @@ int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
     // measured (tools/attn_bench.py, b=512 S=316): forward 4 / 5 / 6 / 8 waves = 330 / 461 / 403 / 360 us (the kernels are
     // LDS-instruction bound, more waves only add contention); backward is faster with 8
     const bool tight = a.S > (NT - 2) * 16;
+    if constexpr (NT == 20 && !CAUSAL) {
+        // round 4: the audio tower's shape (288 < S <= 320) on v_mfma_f32_32x32x16_bf16 (attention_wide.hip); VIPANT_ATTN_FWD=16 keeps
+        // the 16x16x32 kernel of this file for A/B timing
+        static const int variant = attn_env("VIPANT_ATTN_FWD", 32);
+        if (variant != 16 && a.S > 288) return launch_fwd_wide(a, s);
+    }
     return tight ? launch_fwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_fwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
 
@@ -1250,7 +1242,8 @@ int32_t check(const void* qkv, int64_t batch, int64_t S, int64_t H) {
 extern "C" int32_t vipant_mha_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t batch, int64_t S, int64_t H,
                                   int32_t causal, void* stream) {
     if (int32_t e = check(qkv, batch, S, H)) return e;
-    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
+    static const int throttle = attn_env("VIPANT_ATTN_DMA_THROTTLE", 0);       // wide forward: image pieces in flight per wave (0 = all)
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, throttle};
     return causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream);
 }
 

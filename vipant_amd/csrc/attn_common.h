@@ -1,0 +1,33 @@
+// What the attention translation units share (attention.hip: the 16x16x32 kernels and the dispatch; attention_wide.hip: the
+// 32x32x16 kernels of round 4): the argument block, the softmax constants and the wave-uniform buffer descriptor.
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace vipant_attn {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SCALE = 0.125f;              // 1/sqrt(64)
+constexpr float C2 = SCALE * LOG2E;
+
+struct MhaArgs {
+    const bf16_t* qkv; bf16_t* out; float* lse;
+    const bf16_t* dout; float* delta; bf16_t* dqkv;
+    int batch, S, H;
+    int stagger;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
+    // descriptor inputs made provably wave-uniform, otherwise hipcc wraps every buffer op in a waterfall loop
+    const uint64_t a = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return make_rsrc((const void*)(((uint64_t)hi << 32) | lo), (uint32_t)__builtin_amdgcn_readfirstlane(bytes));
+}
+#endif
+
+// attention_wide.hip: forward on v_mfma_f32_32x32x16_bf16 for 288 < S <= 320, no mask (the audio tower's shape)
+int32_t launch_fwd_wide(const MhaArgs& a, hipStream_t s);
+
+}  // namespace vipant_attn

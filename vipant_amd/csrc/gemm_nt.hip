@@ -923,7 +923,10 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
         case VIPANT_EPI_F32: return launch<VIPANT_EPI_F32>(p, s);
         case VIPANT_EPI_RESIDUAL_F32:
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: residual epilogue needs aux");
-            return staged ? launch_persistent<VIPANT_EPI_RESIDUAL_F32>(p, s) : launch<VIPANT_EPI_RESIDUAL_F32>(p, s);
+            // one tile per workgroup: the only caller on the step's path is the last block on its read-out rows (`batch` rows, a handful
+            // of tiles), and the persistent form of this epilogue spilled 42 registers (the fp32 residual tile rides beside the
+            // accumulators); the instantiation is gone, so nothing on the step's path can pick it up again
+            return launch<VIPANT_EPI_RESIDUAL_F32>(p, s);
         case VIPANT_EPI_QUICKGELU:
             VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: quickgelu epilogue needs aux (U out)");
             if (pp) return launch_pp<VIPANT_EPI_QUICKGELU>(p, s);
