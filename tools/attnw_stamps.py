@@ -14,7 +14,8 @@ lib.vipant_debug_attnw_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.vipant_debug_attnw_stamps(buf)
 v = list(buf)
 print("rc", rc)
-print("dma issue", v[1] - v[0], "image wait", v[2] - v[1])
-for it in range(5):
-    print("half-unit", it, "QK", v[4 + 3 * it] - v[3 + 3 * it], "softmax+PV", v[5 + 3 * it] - v[4 + 3 * it], "store/loop", (v[6 + 3 * it] if it < 4 else v[18]) - v[5 + 3 * it])
-print("exchange + last store", v[19] - v[18], "total", v[19] - v[0])
+print("top wait + request", v[2] - v[0])
+names = ["QK(0)", "PV(0)+QK(1)", "PV(1)+QK(2)", "store+", "PV(2)+QK(3)", "PV(3)+QK(4)", "store+", "PV(4)", "exchange+store"]
+for i, nm in enumerate(names):
+    print("%-16s %6d" % (nm, v[4 + i] - v[3 + i]))
+print("total", v[12] - v[0])

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-for th in 0 1 2 3 4 6; do VIPANT_ATTN_DMA_THROTTLE=$th timeout 600 python tools/mha_check.py stag$th 2>&1 | grep "audio\|ViT-L"; done
+for th in 0 97 96; do VIPANT_ATTN_DMA_THROTTLE=$th timeout 600 python tools/mha_check.py probe$th 2>&1 | grep "audio\|ViT-L"; done
