@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 #ifdef VIPANT_ATTN_STAMPS
 __device__ unsigned long long g_attn_stamps[64];
-#define STAMP(i) do { if (blockIdx.x == 3000 && lane == 0 && wave == 1) g_attn_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(i) do { if (prob == 3000 && lane == 0 && wave == 1) g_attn_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -503,12 +503,21 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
     char* doimg = smem + SP * 128;
     char* kimg = smem + 2 * SP * 128;
     char* xbuf = smem + 3 * SP * 128;                 // X[2][SP][32] bf16, 64-byte rows
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = p.H * 64, ld = 3 * D;
-    const int64_t row_base = (int64_t)b * p.S;
+    // Persistent (round 4): one workgroup per CU walks the (batch, head) problems.  A relaunched workgroup costs 1-3 us of start-up
+    // per problem (tools/attnw_trace.py on the forward), and with ONE workgroup per CU nothing runs on the CU meanwhile.
+    const int nprob = p.batch * p.H;
+  for (int prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
+    // (the lane index is laundered per problem: every per-lane address below is then recomputed here instead of being hoisted out
+    // of the problem loop and kept -- or spilled -- across a body that needs all 512 registers)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
     const int kcol = lane & 15, g = lane >> 4;
+    const int b = prob / p.H, h = prob % p.H;
+    const int64_t row_base = (int64_t)b * p.S;
 
     const bf16_t* base = p.qkv + row_base * ld + h * 64;
     const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
@@ -519,13 +528,6 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
     const int64_t stat0 = ((int64_t)b * p.H + h) * p.S;
 
     STAMP(0);
-    // Start-up stagger (first generation of workgroups only, one per CU): with one workgroup per CU nothing overlaps a problem's
-    // load phase (200 KB through a ~10 B/clk port when every CU loads at once), so the CUs are pushed out of lockstep once and stay
-    // apart: a quarter of them is loading while the rest compute.
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const int turns = ((blockIdx.x >> 3) & 3) * p.stagger;
-        for (int i = 0; i < turns; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // the three images first (LDS-DMA, 30 pieces per wave), then the register operands behind them in the same queue
     dma_image(qimg, uniform_rsrc(base, lim), ld * 2, SP / 8, wave, 4, lane);
     dma_image(doimg, uniform_rsrc(dobase, lim_o), D * 2, SP / 8, wave, 4, lane);
@@ -543,20 +545,19 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
             orow[i][1] = *(const bf16x8*)(obase + off + 8);
         }
     }
-    // this wave's key blocks: wave, wave + 4, ...; their K / V rows as B-operand fragments (key on the lane), straight from HBM
+    // this wave's key blocks: wave, wave + 4, ...; their V rows as B-operand fragments (key on the lane) straight from HBM; the K
+    // fragments are read from the K image once it has landed (round 4: 40 KB less through the CU's load path per problem)
     bf16x8 kf[KPW][2], vf[KPW][2];
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
         const int key = (wave + 4 * j) * 16 + kcol;
-        const bf16_t* kp = base + (int64_t)(key < p.S ? key : p.S - 1) * ld + D + 8 * g;      // rows >= S: a copy of row S - 1 (finite)
-        kf[j][0] = *(const bf16x8*)kp;
-        kf[j][1] = *(const bf16x8*)(kp + 32);
-        vf[j][0] = *(const bf16x8*)(kp + D);
-        vf[j][1] = *(const bf16x8*)(kp + D + 32);
+        const bf16_t* kp = base + (int64_t)(key < p.S ? key : p.S - 1) * ld + 2 * D + 8 * g;  // rows >= S: a copy of row S - 1 (finite)
+        vf[j][0] = *(const bf16x8*)kp;
+        vf[j][1] = *(const bf16x8*)(kp + 32);
     }
     STAMP(1);
     // the images are the oldest 30 entries of the queue: wait for them only, then take dO for delta from its LDS image
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 4 * KPW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 2 * KPW) : "memory");
     __builtin_amdgcn_s_barrier();
     STAMP(27);
     // Keys >= S (the image rows behind the problem's last row hold the next sample's data): their P / dS are finite numbers, not
@@ -574,7 +575,13 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
         sacc += __shfl_xor(sacc, 2, 64);
         if ((tid & 3) == 0 && row < p.S) p.delta[stat0 + row] = sacc;
     }
-    __syncthreads();                                   // delta visible to the workgroup (and the K / V fragments have landed)
+    __syncthreads();                                   // delta visible to the workgroup (and the V fragments have landed)
+    const ImgLane il = img_lane(lane);
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {                    // keys >= S: zero rows -- finite P / dS that are never stored
+        kf[j][0] = img_row_frag(kimg, il, wave + 4 * j, 0);
+        kf[j][1] = img_row_frag(kimg, il, wave + 4 * j, 1);
+    }
     // The resident operand fragments live in the ACCUMULATOR half of the register file (MFMA reads A / B operands from there as
     // well): with dK / dV that half is full, so the S / dP products must take architectural VGPRs as their destination -- which is
     // where the exp / dS arithmetic needs them (in AGPRs every score cost a v_accvgpr_read: 180 of 400 VALU instructions per step).
@@ -585,7 +592,6 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
     }
     STAMP(2);
 
-    const ImgLane il = img_lane(lane);
     // row statistics of a 32-query step through bounds-checked buffer loads (rows >= S read as 0 and are masked below)
     const __amdgpu_buffer_rsrc_t rs_lse = uniform_rsrc(p.lse + stat0, (uint32_t)p.S * 4u);
     const __amdgpu_buffer_rsrc_t rs_del = uniform_rsrc(p.delta + stat0, (uint32_t)p.S * 4u);
@@ -837,6 +843,446 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
             }
     }
     STAMP(26);
+    __syncthreads();                                   // every wave has read its staging rows: the next problem's images may land
+  }
+}
+
+// LDS-DMA through inline asm: invisible to hipcc's wait insertion.  (With a builtin piece in flight every transposed-read builtin --
+// no memory operand: "may alias" -- gets an s_waitcnt vmcnt(0) in front; inside a loop that streams its operands that is an HBM
+// round trip per region.)  The caller owns the vmcnt wait and the barrier that publish the bytes.  M0 carries the LDS base.
+__device__ __forceinline__ void lds_dma16_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
+}
+
+__device__ __forceinline__ void lds_dma4_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
+}
+
+// ------------------------------------------------------------------------ backward, ONE pass, streamed operands (round 4)
+// The same five contractions, the same regions and issue groups as mha_bwd1_kernel; what changes is where the operands wait.  There a
+// problem began with 200 KB of loads (Q, dO, K images, K / V fragments) that nothing overlapped -- one workgroup per CU, 13-16 k of
+// 61 k cycles -- because the three images filled the LDS.  Only one 32-query step's rows of Q and dO are ever read at a time, so here
+// they pass through a ring of four 8-KiB stages, requested three steps ahead; the LDS that frees holds a SECOND K image, filled one
+// piece per step while the current problem runs; V fragments for the next problem are requested when the last A stage has issued;
+// delta = rowsum(dO . O) is taken per step from the stage's dO rows and 16 bytes of O per thread and handed over through 128 floats
+// of LDS (no global round trip, no 320-row pass up front).  The workgroup is persistent, the ring runs on across problems: a
+// problem's first steps, its K image, its statistics are all in place when the previous problem's dK / dV leave.
+// LDS: K images 2 x 40 KiB | X 2 x 20 KiB | ring 4 x (Q 4 KiB + dO 4 KiB) | delta 2 x 32 floats | O rows 4 x 1 KiB | lse 4 x 256 B
+// = 157.25 KiB.  NOTHING inside the loop is loaded into registers from global memory: every request is an LDS-DMA piece (inline
+// asm, so that hipcc's wait insertion does not see it; explicit counted vmcnt waits).  An asm load into registers whose wait comes
+// a step later is not safe -- the register allocator may park the "loaded" value elsewhere before the data has arrived -- and a
+// compiler-visible load would be awaited together with every piece in flight.  The O rows and lse words a wave needs for its
+// part of delta / its row constants go to buffers private to the wave: no barrier, only the wave's own wait.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SP = NT * 16, KPW = NT / 4, NU = NT / 2;
+    static_assert(NT == 20 && KPW == 5, "written for 20 key blocks of 16: five per wave, ten 32-query steps");
+    constexpr int KIMG = SP * 128, XB = SP * 64, STG = 8192;
+    char* const xbuf = smem + 2 * KIMG;
+    char* const ring = xbuf + 2 * XB;
+    float* const sdel = (float*)(ring + 4 * STG);      // [2][32]
+    char* const obuf = ring + 4 * STG + 256;           // [4 waves][8 rows x 128 B]: the O rows a wave's threads take delta from
+    char* const lbuf = obuf + 4096;                    // [4 waves][64 floats]: lse of a step's queries (32 used), one copy per wave
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = p.H * 64, ld = 3 * D;
+    const int nprob = p.batch * p.H;
+
+    // ---- what a global step needs from HBM.  Global step = (problem, 32-query step).  Everything per-lane is a constant of the
+    // lane (the swizzle of an 8-row block depends on the row's low three bits only) and everything per-step rides the scalar
+    // offset of a buffer access: a request costs no vector arithmetic inside the hand-scheduled regions.  A problem's base
+    // pointers (one integer division) are made once per problem; past the last problem the descriptors have zero length.
+    struct Prob { const bf16_t* q; const bf16_t* dO; const bf16_t* o; const float* lse; uint32_t limq, limdo; uint32_t any; };
+    auto make_prob = [&](int pr) {
+        Prob t;
+        t.any = pr < nprob ? 1u : 0u;
+        const int pq = t.any ? pr : 0;
+        const int b = pq / p.H, h = pq % p.H;
+        t.q = p.qkv + (int64_t)b * p.S * ld + h * 64;
+        t.dO = p.dout + (int64_t)b * p.S * D + h * 64;
+        t.o = p.out + (int64_t)b * p.S * D + h * 64;
+        t.lse = p.lse + (int64_t)pq * p.S;
+        const int64_t rq = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2, rd = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
+        t.limq = t.any ? (uint32_t)(rq > 0xFFFFFFFFll ? 0xFFFFFFFFll : rq) : 0u;
+        t.limdo = t.any ? (uint32_t)(rd > 0xFFFFFFFFll ? 0xFFFFFFFFll : rd) : 0u;
+        return t;
+    };
+    // per-lane constants (recomputed per problem from the laundered lane index)
+    struct LaneK { uint32_t vq, vdo, vo, vl; };
+    auto make_lanek = [&](int lane) {
+        LaneK k;
+        const int r8 = lane >> 3, c = (lane & 7) ^ img_swz(r8);
+        k.vq = (uint32_t)(r8 * (ld * 2) + c * 16);
+        k.vdo = (uint32_t)(r8 * (D * 2) + c * 16);
+        k.vo = (uint32_t)(r8 * (D * 2) + (lane & 7) * 16);
+        k.vl = (uint32_t)(lane * 4);
+        return k;
+    };
+    // one stage = rows 32 v .. 32 v + 31 of Q (blocks 0-3) and dO (blocks 4-7); wave w brings block w of each: two pieces
+    auto stage_pieces = [&](const Prob& t, int v, int slot, const LaneK& k) {
+        char* st = ring + slot * STG;
+        lds_dma16_asm(uniform_rsrc(t.q, t.limq), st + wave * 1024, k.vq, (uint32_t)((32 * v + 8 * wave) * (ld * 2)));
+        lds_dma16_asm(uniform_rsrc(t.dO, t.limdo), st + 4096 + wave * 1024, k.vdo, (uint32_t)((32 * v + 8 * wave) * (D * 2)));
+    };
+    // K image: 40 blocks of 8 rows, block 4 i + wave is this wave's piece i (0..9)
+    auto k_piece = [&](const Prob& t, int i, char* img, const LaneK& k) {
+        const int blk = 4 * i + wave;
+        lds_dma16_asm(uniform_rsrc(t.q, t.limq), img + blk * 1024, k.vq, (uint32_t)(blk * 8 * (ld * 2) + D * 2));
+    };
+    // the 8 rows of O this wave's threads take delta from (thread: row 8 wave + (lane >> 3), 8 columns from 8 (lane & 7)), one 1-KiB
+    // piece, linear: a thread reads back exactly the 16 bytes its lane brought; rows >= S read as zeros
+    auto o_piece = [&](const Prob& t, int v, const LaneK& k) {
+        lds_dma16_asm(uniform_rsrc(t.o, t.any ? (uint32_t)(((int64_t)(p.S - 1) * D + 64) * 2) : 0u), obuf + wave * 1024, k.vo,
+                      (uint32_t)((32 * v + 8 * wave) * (D * 2)));
+    };
+    // lse of a step's 32 queries (64 floats fetched, one per lane; rows >= S read as 0 and are masked by the caller)
+    auto lse_piece = [&](const Prob& t, int v, const LaneK& k) {
+        lds_dma4_asm(uniform_rsrc(t.lse, t.any ? (uint32_t)p.S * 4u : 0u), lbuf + wave * 256, k.vl, (uint32_t)(v * 128));
+    };
+    // delta of one step from the stage's dO rows and the wave's O rows: 8 lanes share a row; three DPP adds (quad xor 1, quad xor 2,
+    // then the mirror of each 8-lane half row, which pairs the two quads)
+    auto delta_step = [&](int slot, int dbuf, int tid, int lane) {
+        const int row = tid >> 3, c0 = tid & 7;
+        const v4i32_t dw = *(const v4i32_t*)(ring + slot * STG + 4096 + row * 128 + ((c0 ^ img_swz(row)) << 4));
+        const v4i32_t ow = *(const v4i32_t*)(obuf + wave * 1024 + lane * 16);
+        const bf16x8 d0 = __builtin_bit_cast(bf16x8, dw), o0 = __builtin_bit_cast(bf16x8, ow);
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc += (float)d0[e] * (float)o0[e];
+        // (v_dot2_f32_bf16 in place of the converts and multiply-adds gave wrong sums inside this kernel although a stand-alone probe
+        // of the instruction passes -- tools/probes/dot2_dpp_probe.hip -- not pursued; the three DPP adds replace three ds_bpermute
+        // round trips, which at one wave per SIMD are exposed latency)
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xF, 0xF, true));
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xF, 0xF, true));
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xF, 0xF, true));
+        if (c0 == 0) sdel[dbuf * 32 + row] = sacc;
+    };
+
+    // ---- preamble: the first problem's K image, its first three stages, its V fragments, lse of step 0, O of steps 0 and 1
+    int prob = blockIdx.x;
+    int gs = 0;                                        // global step counter: ring slot = gs & 3, delta buffer = gs & 1
+    int cur = 0;                                       // K image in use
+    bf16x8 vf[KPW][2];
+    auto v_load = [&](const Prob& t, int lane) {
+        const int kcol = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            const int key = (wave + 4 * j) * 16 + kcol;
+            const bf16_t* kp = t.q + (int64_t)(key < p.S ? key : p.S - 1) * ld + 2 * D + 8 * g;      // rows >= S: row S - 1 (finite)
+            v4i32_t t0, t1;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&a"(t0), "=&a"(t1) : "v"(kp) : "memory");
+            vf[j][0] = __builtin_bit_cast(bf16x8, t0); vf[j][1] = __builtin_bit_cast(bf16x8, t1);
+        }
+    };
+    Prob pc = make_prob(prob);
+    {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int tid = wave * 64 + lane;
+        const LaneK lk = make_lanek(lane);
+        for (int i = 0; i < 10; ++i) k_piece(pc, i, smem, lk);
+        stage_pieces(pc, 0, 0, lk);
+        stage_pieces(pc, 1, 1, lk);
+        stage_pieces(pc, 2, 2, lk);
+        v_load(pc, lane);
+        lse_piece(pc, 0, lk);
+        o_piece(pc, 0, lk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        delta_step(0, 0, tid, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the O rows are read: the piece for step 1 may overwrite them
+        o_piece(pc, 1, lk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (in the steady state the last step of the previous problem waits for it)
+    }
+
+  for (; prob < nprob; prob += gridDim.x, cur ^= 1) {
+    // (the lane index is laundered per problem: per-lane addresses are recomputed here instead of being kept across the loop)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    const int kcol = lane & 15, g = lane >> 4;
+    const LaneK lk = make_lanek(lane);
+    const Prob pn = make_prob(prob + gridDim.x);
+    char* const kimg = smem + cur * KIMG;
+    char* const knext = smem + (cur ^ 1) * KIMG;
+
+    STAMP(0);
+    // ---- problem switch: the K image landed during the previous problem (its last piece was awaited at that problem's end)
+    for (int i = p.S * 8 + tid; i < SP * 8; i += 256) *(u32x4*)(kimg + i * 16) = u32x4{0u, 0u, 0u, 0u};      // keys >= S
+    __syncthreads();                                   // ... and delta of step 0 is visible
+    const ImgLane il = img_lane(lane);
+    bf16x8 kf[KPW][2];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        kf[j][0] = img_row_frag(kimg, il, wave + 4 * j, 0);
+        kf[j][1] = img_row_frag(kimg, il, wave + 4 * j, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        asm volatile("" : "+a"(kf[j][0])); asm volatile("" : "+a"(kf[j][1]));
+        asm volatile("" : "+a"(vf[j][0])); asm volatile("" : "+a"(vf[j][1]));
+    }
+
+    // dQ rows of this (batch, head): stores of rows >= S (and of the step before the first) go out of range and are dropped
+    bf16_t* const dq_base = p.dqkv + (pc.q - p.qkv);  // the same (batch, head) offset in the gradient buffer
+    const __amdgpu_buffer_rsrc_t rs_dq = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 64) * 2));
+    auto load_rows = [&](const char* st, bf16x8 (&qr)[2][2], bf16x8 (&dr)[2][2]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                qr[tt][ds] = img_row_frag(st, il, tt, ds);
+                dr[tt][ds] = img_row_frag(st + 4096, il, tt, ds);
+            }
+    };
+    auto load_tr = [&](const char* st, bf16x8 (&qtr)[4], bf16x8 (&dot)[4]) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { qtr[dt] = img_tr_frag(st, il, 0, dt); dot[dt] = img_tr_frag(st + 4096, il, 0, dt); }
+    };
+    // row constants of a step: -lse * log2e (queries >= S: -inf) from the raw words, -delta from the hand-over buffer
+    auto make_stats = [&](int u, int dbuf, f32x4 (&nl)[2], f32x4 (&ndl)[2]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int q0 = u * 32 + tt * 16 + g * 4;
+            const f32x4 lv = *(const f32x4*)(lbuf + wave * 256 + (tt * 16 + g * 4) * 4);
+            const f32x4 dv4 = *(const f32x4*)(sdel + dbuf * 32 + tt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nl[tt][r] = q0 + r < p.S ? -lv[r] * LOG2E : -INFINITY;
+                ndl[tt][r] = -dv4[r];
+            }
+        }
+    };
+    const uint32_t xswz = (uint32_t)((kcol >> 2) & 1) * 32u;
+    const uint32_t xw0 = (uint32_t)(kcol * 64 + g * 8) + xswz, xw1 = (uint32_t)(kcol * 64 + g * 8) + (32u ^ xswz);
+    const int qt2 = wave & 1, dtp = wave >> 1;
+    const int xra = 4 * g + ((lane >> 2) & 3);
+    const uint32_t xrd = (uint32_t)(xra * 64 + ((qt2 ^ (g & 1)) * 32) + (lane & 3) * 8);
+    const uint32_t ka0 = dtp ? il.tr[2] : il.tr[0], ka1 = dtp ? il.tr[3] : il.tr[1];
+    auto tr_pair = [&](const char* pa, uint32_t second) {
+        const bf16x4 lo = lds_read_tr16(pa);
+        const bf16x4 hi = lds_read_tr16(pa + second);
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    };
+
+    f32x4 dk[KPW][4], dv[KPW][4];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    bf16x8 qr[2][2], dr[2][2], qtr[4], dot[4];
+    f32x4 nl[2], ndl[2];
+    f32x4 sa[2][2], dp[2][2];
+    f32x4 p2[2], ds2[2];
+    bf16x8 pf_c, dsf_c;
+    f32x4 dq0, dq1;
+    bf16x8 xfa, k0a, k1a, xfb, k1b, k0b;
+    auto s_mfma = [&](auto jc, auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, par = j & 1;
+        if ((i & 3) == 0) sa[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[tt][0], kf[j][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if ((i & 3) == 1) dp[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[tt][0], vf[j][0], ndl[tt], 0, 0, 0);
+        if ((i & 3) == 2) sa[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[tt][1], kf[j][1], sa[par][tt], 0, 0, 0);
+        if ((i & 3) == 3) dp[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[tt][1], vf[j][1], dp[par][tt], 0, 0, 0);
+    };
+    auto a_mfma = [&](auto jc, auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, dt = i >> 1;
+        if (i & 1) dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf_c, dk[j][dt], 0, 0, 0);
+        else dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pf_c, dv[j][dt], 0, 0, 0);
+    };
+    auto p_mfma = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i == 0) dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0a, xfa, dq0, 0, 0, 0);
+        if (i == 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1a, xfa, dq1, 0, 0, 0);
+        if (i == 2) dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0b, xfb, dq0, 0, 0, 0);
+        if (i == 3) dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1b, xfb, dq1, 0, 0, 0);
+    };
+    auto p_load = [&](auto ic, const char* xr, int uk) {
+        constexpr int i = decltype(ic)::value;
+        if (i == 0) xfa = tr_pair(xr + uk * 2048, 1024);
+        if (i == 1) k0a = tr_pair(kimg + ka0 + uk * 4096, 2048);
+        if (i == 2) k1a = tr_pair(kimg + ka1 + uk * 4096, 2048);
+        if (i == 3) xfb = tr_pair(xr + (uk + 1) * 2048, 1024);
+        if (i == 4) k0b = tr_pair(kimg + ka0 + (uk + 1) * 4096, 2048);
+        if (i == 5) k1b = tr_pair(kimg + ka1 + (uk + 1) * 4096, 2048);
+    };
+    float tf[2];
+    auto v_f = [&](auto jc, auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, r = i & 3, par = j & 1;
+        tf[i & 1] = sa[par][tt][r] * C2 + nl[tt][r];
+    };
+    auto v_e = [&](auto ic) {
+        constexpr int i = decltype(ic)::value, tt = i >> 2, r = i & 3;
+        p2[tt][r] = __builtin_amdgcn_exp2f(tf[i & 1]);
+    };
+    auto v_m = [&](auto jc, auto ic) {
+        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, r = i & 3, par = j & 1;
+        ds2[tt][r] = p2[tt][r] * dp[par][tt][r];
+    };
+    auto dq_store = [&](int u, bool on) {
+        const int q = u * 32 + qt2 * 16 + kcol;
+        const uint32_t off = (on && q < p.S) ? (uint32_t)(((int64_t)q * ld + dtp * 32 + g * 4) * 2) : 0xFFFFFFF0u;
+        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x4_to_bf16x4(dq0 * SCALE)), rs_dq, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x4_to_bf16x4(dq1 * SCALE)), rs_dq, off, 32, 0);
+    };
+    auto region = [&](auto jc, char* xw, const char* xr, const char* st_next) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int nS = J + 1 < KPW ? 8 : 0, nA = J >= 1 ? 8 : 0;
+        bf16x8 pf_n, dsf_n;
+        auto mfma_n = [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n < nS) s_mfma(Int2<(J + 1 < KPW ? J + 1 : 0)>{}, Int2<(n < nS ? n : 0)>{});
+            else if constexpr (n < nS + nA) a_mfma(Int2<(J >= 1 ? J - 1 : 0)>{}, Int2<(n - nS) & 7>{});
+            else if constexpr (n < nS + nA + 4) p_mfma(Int2<(n - nS - nA) & 3>{});
+        };
+        auto group = [&](auto gc) {
+            constexpr int gi = decltype(gc)::value;
+            if constexpr (gi < 6) p_load(Int2<gi>{}, xr, 2 * J);
+            mfma_n(Int2<2 * gi>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (gi < 8) v_e(Int2<(gi < 8 ? gi : 0)>{});
+            if constexpr (gi >= 1 && gi <= 8) v_m(jc, Int2<(gi >= 1 && gi <= 8 ? gi - 1 : 0)>{});
+            if constexpr (gi == 8) pf_n = pack8_pairs(p2[0], p2[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_n(Int2<2 * gi + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (gi < 7) v_f(jc, Int2<(gi < 7 ? gi + 1 : 0)>{});
+            if constexpr (gi == 9 && J + 1 < KPW) v_f(Int2<(J + 1 < KPW ? J + 1 : 0)>{}, Int2<0>{});
+            if constexpr (gi == 9) dsf_n = pack8_pairs(ds2[0], ds2[1]);
+            if constexpr (gi == 9) {
+                const u32x4 dw = __builtin_bit_cast(u32x4, dsf_n);
+                typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                *(u32x2_t*)(xw + J * 4096 + xw0) = u32x2_t{dw[0], dw[1]};
+                *(u32x2_t*)(xw + J * 4096 + xw1) = u32x2_t{dw[2], dw[3]};
+                if (J == KPW - 1) load_rows(st_next, qr, dr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        group(Int2<0>{}); group(Int2<1>{}); group(Int2<2>{}); group(Int2<3>{}); group(Int2<4>{});
+        group(Int2<5>{}); group(Int2<6>{}); group(Int2<7>{}); group(Int2<8>{}); group(Int2<9>{});
+        pf_c = pf_n; dsf_c = dsf_n;
+    };
+
+    // ---- step 0's operands: its stage landed long ago, its statistics came with the previous problem's last step (or the preamble)
+    load_rows(ring + (gs & 3) * STG, qr, dr);
+    make_stats(0, gs & 1, nl, ndl);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { qtr[dt] = bf16x8{}; dot[dt] = bf16x8{}; }
+    pf_c = bf16x8{}; dsf_c = bf16x8{};
+    STAMP(1);
+    for (int u = 0; u < NU; ++u, ++gs) {
+        char* xw = xbuf + (u & 1) * XB + wave * 1024;
+        const char* xr = xbuf + ((u & 1) ^ 1) * XB + xrd;              // X of step u - 1
+        const char* st = ring + (gs & 3) * STG;
+        // which (problem, step) the look-ahead requests of this step belong to
+        const Prob& pr1 = u + 1 < NU ? pc : pn; const int v1 = u + 1 < NU ? u + 1 : u + 1 - NU;
+        const Prob& pr2 = u + 2 < NU ? pc : pn; const int v2 = u + 2 < NU ? u + 2 : u + 2 - NU;
+        const Prob& pr3 = u + 3 < NU ? pc : pn; const int v3 = u + 3 < NU ? u + 3 : u + 3 - NU;
+        // head: the previous step's last A stage (zeros at u = 0), this step's transposed fragments, the first S stage
+        a_mfma(Int2<KPW - 1>{}, Int2<0>{}); a_mfma(Int2<KPW - 1>{}, Int2<1>{}); a_mfma(Int2<KPW - 1>{}, Int2<2>{}); a_mfma(Int2<KPW - 1>{}, Int2<3>{});
+        a_mfma(Int2<KPW - 1>{}, Int2<4>{}); a_mfma(Int2<KPW - 1>{}, Int2<5>{}); a_mfma(Int2<KPW - 1>{}, Int2<6>{}); a_mfma(Int2<KPW - 1>{}, Int2<7>{});
+        // delta of the NEXT step from the O rows requested a step ago; then this step's requests, oldest first: lse of the next
+        // step, O of the step after next, [this step's three image pieces], [this step's two dQ stores]
+        delta_step((gs + 1) & 3, (gs + 1) & 1, tid, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's O rows and lse words are in registers: their buffers may be refilled
+        lse_piece(pr1, v1, lk);
+        o_piece(pr2, v2, lk);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tr(st, qtr, dot);
+        s_mfma(Int2<0>{}, Int2<0>{}); s_mfma(Int2<0>{}, Int2<1>{}); s_mfma(Int2<0>{}, Int2<2>{}); s_mfma(Int2<0>{}, Int2<3>{});
+        s_mfma(Int2<0>{}, Int2<4>{}); s_mfma(Int2<0>{}, Int2<5>{}); s_mfma(Int2<0>{}, Int2<6>{}); s_mfma(Int2<0>{}, Int2<7>{});
+        dq0 = f32x4{0.f, 0.f, 0.f, 0.f}; dq1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        v_f(Int2<0>{}, Int2<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const char* st_next = ring + ((gs + 1) & 3) * STG;
+        region(Int2<0>{}, xw, xr, st_next);
+        // the ring slot of the PREVIOUS step is free (its last readers finished before that step's barrier): rows of global step + 3
+        stage_pieces(pr3, v3, (gs + 3) & 3, lk);
+        region(Int2<1>{}, xw, xr, st_next);
+        k_piece(pn, u, knext, lk);
+        region(Int2<2>{}, xw, xr, st_next);
+        region(Int2<3>{}, xw, xr, st_next);
+        region(Int2<4>{}, xw, xr, st_next);
+        dq_store(u - 1, u > 0);
+        if (u == 5) STAMP(20);
+        // everything but this step's three pieces and two stores: the lse words, the O words, and every older piece
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        make_stats(v1, (gs + 1) & 1, nl, ndl);
+        STAMP(2 + u);
+    }
+    auto a_stage = [&](auto jc, const bf16x8& pf, const bf16x8& dsf) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pf, dv[j][dt], 0, 0, 0);
+            dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, dk[j][dt], 0, 0, 0);
+        }
+    };
+    auto p_stage = [&](const char* xr, int uk0, int n) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const int uk = uk0 + i;
+            const bf16x8 xf = tr_pair(xr + uk * 2048, 1024);
+            const bf16x8 k0 = tr_pair(kimg + ka0 + uk * 4096, 2048), k1 = tr_pair(kimg + ka1 + uk * 4096, 2048);
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, xf, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, xf, dq1, 0, 0, 0);
+        }
+    };
+    a_stage(Int2<KPW - 1>{}, pf_c, dsf_c);
+    // the V fragments' registers are free: request the next problem's (awaited at the end of this problem, behind the dK / dV stores)
+    v_load(pn, lane);
+    dq0 = f32x4{0.f, 0.f, 0.f, 0.f}; dq1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    p_stage(xbuf + ((NU - 1) & 1) * XB + xrd, 0, NU);
+    dq_store(NU - 1, true);
+    STAMP(12);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave is done with this K image and with X: they become the staging area
+    // dK / dV through LDS so that they leave as whole 128-byte rows, 16 B per lane.  Row (key) = 256 B: dK | dV; 8-byte granules XOR-ed
+    // with an even number per key (conflict-free writes, and a 16-byte chunk stays a chunk).  Waves 0, 1: the dead K image; 2, 3: X.
+    {
+        const __amdgpu_buffer_rsrc_t rs_dkv = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 2 * D + 64) * 2));
+        STAMP(13);
+        char* stg = (wave < 2 ? kimg : xbuf) + (wave & 1) * (KPW * 4096);
+#pragma unroll
+        for (int j = 0; j < KPW; ++j)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint32_t sw = (uint32_t)(kcol & 7) << 1;
+                *(bf16x4*)(stg + j * 4096 + kcol * 256 + (((uint32_t)(dt * 4 + g) ^ sw) << 3)) = f32x4_to_bf16x4(dk[j][dt] * SCALE);
+                *(bf16x4*)(stg + j * 4096 + kcol * 256 + (((uint32_t)(16 + dt * 4 + g) ^ sw) << 3)) = f32x4_to_bf16x4(dv[j][dt]);
+            }
+#pragma unroll
+        for (int j = 0; j < KPW; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kr_ = i * 4 + (lane >> 4), c = lane & 15;
+                const int key = (wave + 4 * j) * 16 + kr_;
+                const bf16x8 v = *(const bf16x8*)(stg + j * 4096 + kr_ * 256 + ((c ^ (kr_ & 7)) << 4));
+                // rows >= S: redirected out of the descriptor's range and dropped, so that every wave issues exactly 20 stores
+                const uint32_t off = key < p.S ? (uint32_t)(((int64_t)key * ld + D + (c >> 3) * D + (c & 7) * 8) * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dkv, off, 0, 0);
+            }
+    }
+    STAMP(14);
+    // the next problem's V fragments (10 loads) went out before this problem's 2 + 20 stores
+    asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // staging rows read: X may be written again; (the other K image is complete:
+    STAMP(15);
+    pc = pn;
+  }                                                    // its last piece was awaited at the end of step 9)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1133,6 +1579,9 @@ int32_t launch_stream(const MhaArgs& a, hipStream_t s) {
     return VIPANT_OK;
 }
 
+template <int NT>
+int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s);
+
 // VIPANT_ATTN_BWD=2: the two-pass backward (round 2) for A/B timing; VIPANT_ATTN_STAGGER: see mha_bwd1_kernel
 int attn_env(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -1185,11 +1634,37 @@ int32_t launch_bwd1(const MhaArgs& a, hipStream_t s) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
-    hipLaunchKernelGGL((mha_bwd1_kernel<NT>), dim3(a.batch * a.H), dim3(256), lds, s, a);
+    static int cus = 0;                              // one persistent workgroup per CU (all 160 KiB of LDS)
+    if (!cus) {
+        int dev = 0;
+        VIPANT_HIP_TRY(hipGetDevice(&dev));
+        VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int nprob = a.batch * a.H;
+    const int grid = attn_env("VIPANT_ATTN_BWD_PERSIST", 1) ? (nprob < cus ? nprob : cus) : nprob;
+    hipLaunchKernelGGL((mha_bwd1_kernel<NT>), dim3(grid), dim3(256), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
+
+template <int NT>
+int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024;
+    static bool configured = false;
+    static int cus = 0;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        VIPANT_HIP_TRY(hipGetDevice(&dev));
+        VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        configured = true;
+    }
+    const int nprob = a.batch * a.H;
+    hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
 
 // EDGE = 2 when only the last two key tiles can be partial (S > (NT - 2) * 16), else every tile carries mask code.
 template <int NT, bool CAUSAL>
@@ -1209,8 +1684,11 @@ int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
 template <int NT, bool CAUSAL>
 int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
     const bool tight = a.S > (NT - 2) * 16;
-    static const int variant = attn_env("VIPANT_ATTN_BWD", 1);
+    static const int variant = attn_env("VIPANT_ATTN_BWD", 3);
     if constexpr (NT == 20 && !CAUSAL) {
+        // VIPANT_ATTN_BWD: 3 (default) = single pass with streamed operands (round 4), 1 = single pass with resident images
+        // (round 3), 2 = the two passes of round 2
+        if (variant == 3) return launch_bwd1s<NT>(a, s);
         if (variant == 1) return launch_bwd1<NT>(a, s);
     }
     if (NT >= 8 && attn_waves() == 8)
