@@ -36,7 +36,7 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=Fa
     return (layers - 1) * full + last + 2 * P * kpatch * width + 2 * width * embed if layers > 0 else 2 * P * kpatch * width + 2 * width * embed
 
 
-PMC_FILE = "profiles/r3_pmc_traffic.json"
+PMC_FILE = "profiles/r3_pmc_traffic.json"      # (same kernel and shape this round: not re-collected)
 
 
 def pmc_traffic(M, N, K):
@@ -346,9 +346,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ms = dt / args.steps * 1e3
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    live_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(len(events), 1)
+    # The roofline figure of the dominant kernel comes from a short SERIAL post-pass (outside the timed region): the same step with the
+    # frozen image tower on the main stream, so that the HIP events around a c_fc launch bracket that launch and nothing else -- the
+    # condition the committed rocprofv3 per-shape tables are taken under (profiles/*_kernel_shapes_serial.txt).  In the timed steps
+    # the image tower's launches on the side stream share the chip with the bracketed launch: that number stays as `in_step_*`.
+    overlap_was = os.environ.get("VIPANT_TOWER_OVERLAP")
+    os.environ["VIPANT_TOWER_OVERLAP"] = "0"
+    ops.KERNEL_PROBE["gemm_nt"] = {"events": [], "match": lambda epi, M, N, K: epi == ops.EPI_QUICKGELU_D8 and M == Mrows}
+    for i in range(3):
+        one_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    serial_events = ops.KERNEL_PROBE.pop("gemm_nt")["events"]
+    if overlap_was is None:
+        del os.environ["VIPANT_TOWER_OVERLAP"]
+    else:
+        os.environ["VIPANT_TOWER_OVERLAP"] = overlap_was
+    serial_events = serial_events[len(serial_events) // 3:]          # the first of the three steps settles clocks and caches
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in serial_events) / max(len(serial_events), 1)
     kern_flops = 2.0 * Mrows * (4 * W) * W
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    live = kern_flops / (live_ms * 1e-3) / 1e12 if live_ms > 0 else 0.0
     P = S - 1
     lbr = not args.full_last_block
     step_flops = b * (3 * tower_fwd_flops(S, 1024, P, width=W, layers=args.layers, last_block_rows=lbr)
@@ -371,7 +389,10 @@ def main():
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(Mrows, 4 * W, W), "traffic_source": PMC_FILE,
                      "algorithmic_flops": kern_flops, "algorithmic_bytes": 2.0 * (Mrows * W + 4 * W * W) + 3.0 * Mrows * 4 * W,
-                     "launches_timed": len(events), "avg_launch_ms": round(kern_ms, 4)},
+                     "launches_timed": len(serial_events), "avg_launch_ms": round(kern_ms, 4),
+                     "timing": "HIP events around each launch in a serial post-pass (image tower on the main stream, 2 of 3 extra steps)",
+                     "in_step_avg_launch_ms": round(live_ms, 4), "in_step_frac": round(live / PEAK_BF16_TFLOPS, 4),
+                     "in_step_launches_timed": len(events)},
     }
     if rank == 0:
         # the InfoNCE kernel group alone (loss + all three gradients) at the 8-GPU global batch B = 4096
@@ -389,7 +410,8 @@ def main():
         torch.cuda.synchronize()
         nce_ms = e0.elapsed_time(e1) / 10
         out["infonce_alone"] = {"B": Bn, "E": E, "ms": round(nce_ms, 4), "tflops": round(6.0 * Bn * Bn * E / (nce_ms * 1e-3) / 1e12, 1),
-                                "note": "loss + dx1 + dx2 + dlogit_scale, B x B logits never stored"}
+                                "note": "loss + dx1 + dx2 + dlogit_scale; the B x B fp32 logits are never stored, the bf16 s.dZ matrix and its transpose "
+                                        "(2 x 32 MiB at B = 4096) are, between pass 2 and the gradient contraction"}
         if world == 1 and lbr and not args.no_full_last_block_check:
             # transparency: the same build, same box, with the towers' last block evaluated on EVERY token (what the reference
             # computes before its read-out discards all rows but one) -- a short untimed-region extra, never `value`

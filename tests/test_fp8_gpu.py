@@ -206,3 +206,44 @@ def test_e4m3_stack_with_recomputed_mlp_is_bit_identical(ops):
         outs.append((y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in bb.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert all(torch.equal(a, c) for a, c in zip(outs[0][2], outs[1][2]))
+
+
+def test_e4m3_block_width_1024_against_oracle():
+    """BASELINE.json configs[4] width (ViT-L: 1024, 16 heads) with e4m3 contractions against the CPU ORACLE (oracle/ref_cpu.py, fp32
+    restatement of cvap/module/val.py:468-522), not against the bf16 HIP run: two blocks forward + backward at S = 50.  The
+    reference has no fp8 path, so the budgets are about twice what MI355X shows for this format (per-row power-of-two scales,
+    e4m3 operands in the eight NT contractions of a block); the bf16 stack on the same weights is checked beside it so that the
+    e4m3 budget can be read as "bf16 error x k"."""
+    import vipant_amd.module as Mod
+    from oracle import ref_cpu as R
+    from types import SimpleNamespace as NS
+    import gen
+    Dw, S_, b_, layers = 1024, 50, 4, 2
+    w = gen.det_weights(f"wide/{Dw}", gen.backbone_shapes(Dw, layers))
+    sd = {k[len("encoder."):]: v for k, v in w.items()}
+    x = gen.det_randn(f"wide/{Dw}/x", (b_, S_, Dw))
+    gy = gen.det_randn(f"wide/{Dw}/gy", (b_, S_, Dw))
+    xr = x.clone().requires_grad_()
+    sdr = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    yr = R.transformer_backbone(xr, sdr, "", layers, Dw, None, True)
+    yr.backward(gy)
+
+    def rel_l2(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    res = {}
+    for fp8 in (False, True):
+        bb = Mod.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=Dw, ctx_len=None)
+        bb.load_state_dict(sd, strict=True)
+        bb = bb.to(DEV)
+        bb.fp8 = fp8
+        xg = x.to(DEV).requires_grad_()
+        y = bb(xg)
+        y.backward(gy.to(DEV))
+        worst = max(rel_l2(p.grad, sdr[k].grad) for k, p in bb.named_parameters())
+        res[fp8] = (rel_l2(y.detach(), yr.detach()), rel_l2(xg.grad, xr.grad), worst)
+    print(f"width 1024 vs oracle (output, input gradient, worst parameter gradient rel-L2): bf16 {res[False]}, e4m3 {res[True]}")
+    assert res[False][0] < 1e-2 and res[False][1] < 2e-2 and res[False][2] < 4e-2, res[False]
+    # e4m3 observed on MI355X: output 3.4e-2, input gradient 4.6e-2, worst parameter gradient 8.4e-2 (r4_parity_observed.jsonl)
+    assert res[True][0] < 8e-2 and res[True][1] < 1e-1 and res[True][2] < 2e-1, res[True]

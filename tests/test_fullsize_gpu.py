@@ -195,6 +195,51 @@ def test_full_size_last_block_rows_match_full_block():
     assert diffs[0][0] < 5e-2, diffs[0]
 
 
+def test_full_size_at_step():
+    """BASELINE.json configs[2] shape on one GPU at full size: AT fine-tuning layout -- 512 clips, audio ViT-B (12 blocks, S = 316) +
+    the frozen 12-block causal text transformer at 77 tokens with its end-of-text read-out rows + VALCELossHead(al).  The step-0 loss
+    equals the ORACLE's loss head on the features the HIP towers produce (<= 1e-4), and the two towers' last blocks on their read-out
+    rows (`running.last_block_rows`, the default: class row for audio, the end-of-text row of each caption for text) agree with the
+    full last blocks in features, loss and every audio gradient."""
+    import vipant_amd.module as M
+    from oracle import ref_cpu as R
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_model_gpu import audio_cfg, text_cfg
+    aud = gen.det_randn("full/at/aud", (B, 1, 1024, 128)).to(DEV)
+    tok = gen.det_tokens("full/at/tok", B).to(DEV)
+    assert tok.shape == (B, 77)
+    runs = []
+    for rows in (False, True):
+        head = M.build_audio_head(audio_cfg(1024, 128, 12))
+        head.load_state_dict(gen.det_weights("e2e/cfg2", gen.vit_head_shapes(768, 12, 512, S)), strict=True)
+        thead = M.build_text_head(text_cfg(12))
+        thead.load_state_dict(gen.det_weights("text/l12", gen.text_head_shapes(512, 12, 512)), strict=True)
+        lhead = M.build_loss_head(NS(name="VALCELossHead", layers=[], scaling=True, scale_max=None, va=False, lv=False, al=True))
+        head, thead, lhead = head.to(DEV).train(), thead.to(DEV).eval(), lhead.to(DEV).train()
+        for q in thead.parameters():
+            q.requires_grad = False
+        head.encoder.last_block_rows = rows
+        thead.encoder.last_block_rows = rows
+        feat = head(aud, normalized=True)
+        with torch.no_grad():
+            tf = thead(tok, normalized=True)
+        loss = lhead(None, feat, tf, normalized=True)
+        loss.backward()
+        ls = {"al": lhead.loss_head_al.logit_scale.detach().cpu().clone()}
+        loss_oracle = float(R.valce_loss_head(None, feat.detach().cpu(), tf.cpu(), ls, va=False, lv=False, al=True))
+        assert abs(float(loss) - loss_oracle) < 1e-4, (rows, float(loss), loss_oracle)
+        runs.append((feat.detach().clone(), tf.clone(), float(loss), {k: p.grad.double() for k, p in head.named_parameters()}))
+        del head, thead, lhead, feat, loss
+        torch.cuda.empty_cache()
+    (f0, t0, l0, g0), (f1, t1, l1, g1) = runs
+    diffs = sorted(((float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)), k) for k in g0), reverse=True)
+    print(f"full-size AT step, read-out rows vs full last blocks: audio feature max rel diff {max_rel(f1, f0):.2e}, text {max_rel(t1, t0):.2e}, "
+          f"loss {l0:.5f} / {l1:.5f}, worst gradient rel-L2 diff {diffs[0][0]:.3e} ({diffs[0][1]}), median {diffs[len(diffs) // 2][0]:.3e}")
+    assert max_rel(f1, f0) < 1e-2 and max_rel(t1, t0) < 1e-2, (max_rel(f1, f0), max_rel(t1, t0))
+    assert abs(l1 - l0) < 1e-3, (l0, l1)
+    assert diffs[0][0] < 5e-2, diffs[0]
+
+
 def test_vit_l_depth_sample_independence(ops):
     """BASELINE.json configs[4] tower (audio ViT-L: 24 blocks, width 1024, 16 heads, S = 316) with e4m3 contractions and recomputed
     MLP activations: a sample's outputs and input gradients in a 16-clip batch equal, bit for bit, those of 4-clip runs; the weight

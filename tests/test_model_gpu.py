@@ -666,7 +666,11 @@ def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
             else:
                 worst_norm = max(worst_norm, abs(dn / ref - 1))
     observe(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
-    assert worst_loss < 5e-3, worst_loss                  # b = 8: the bf16 towers' loss error at this batch size (observed ~2e-3)
+    # b = 8, two blocks: the bf16 towers' loss error at this batch size.  Observed on MI355X (profiles/r4_parity_observed.jsonl), worst
+    # of four steps: VA 1.7e-3 ... 3.0e-3 over the four (stream, last-block) corners, AT 2.7e-3 (fp32 stream, full block), 3.5e-3 / 3.6e-3
+    # (one of the two round-3 defaults on), 4.05e-3 (both): each default adds ~0.5-0.9e-3 at this size, neither owns the change.  The
+    # budget is 2x the largest observed value.
+    assert worst_loss < 8e-3, worst_loss
     assert worst_norm < 6e-2, worst_norm                  # update norms: LARS trust ratio x gradient norm, bf16 gradient noise
     for k, p in named:
         if f"final_{k}" in g.files:

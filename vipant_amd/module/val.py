@@ -6,7 +6,8 @@ initialisation as the reference, so seeds and checkpoints carry over); their for
 Differences that are deliberate and MI355X-motivated:
   * activations are batch-first token-major [b, S, D] end to end (`TransformerBackbone.batch_first = True`), so
     MetaHead's two permute copies (clip_head.py:108-110) disappear;
-  * the residual stream between blocks is fp32, MFMA operands bf16.
+  * the residual stream is fp16 inside a transformer stack (`running.stream_dtype`, the reference's own autocast precision;
+    `fp32` selectable) and fp32 at the stack's boundaries; its gradient is bf16; MFMA operands are bf16, accumulation fp32.
 """
 from __future__ import annotations
 
