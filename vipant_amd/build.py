@@ -29,7 +29,7 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # resident operand fragments take the AGPRs (pinned there by "+a" constraints in the source); the two-waves-per-SIMD kernels of the
 # file were VGPR-form already.
 EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"],
-                "attention_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+                "attention_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]}
 
 
 _REMARK_ECHO = re.compile(r"^\s*(\d+ \||\|)")      # the source-line echo clang prints under each remark

@@ -847,21 +847,6 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
   }
 }
 
-// LDS-DMA through inline asm: invisible to hipcc's wait insertion.  (With a builtin piece in flight every transposed-read builtin --
-// no memory operand: "may alias" -- gets an s_waitcnt vmcnt(0) in front; inside a loop that streams its operands that is an HBM
-// round trip per region.)  The caller owns the vmcnt wait and the barrier that publish the bytes.  M0 carries the LDS base.
-__device__ __forceinline__ void lds_dma16_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
-    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
-}
-
-__device__ __forceinline__ void lds_dma4_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
-    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
-}
-
 // ------------------------------------------------------------------------ backward, ONE pass, streamed operands (round 4)
 // The same five contractions, the same regions and issue groups as mha_bwd1_kernel; what changes is where the operands wait.  There a
 // problem began with 200 KB of loads (Q, dO, K images, K / V fragments) that nothing overlapped -- one workgroup per CU, 13-16 k of
@@ -1688,7 +1673,8 @@ int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
     if constexpr (NT == 20 && !CAUSAL) {
         // VIPANT_ATTN_BWD: 3 (default) = single pass with streamed operands (round 4), 1 = single pass with resident images
         // (round 3), 2 = the two passes of round 2
-        if (variant == 3) return launch_bwd1s<NT>(a, s);
+        if (variant == 4 && a.S > 288) return launch_bwd_wide(a, s);       // 32x32x16 MFMAs (attention_wide.hip)
+        if (variant == 3 || variant == 4) return launch_bwd1s<NT>(a, s);
         if (variant == 1) return launch_bwd1<NT>(a, s);
     }
     if (NT >= 8 && attn_waves() == 8)

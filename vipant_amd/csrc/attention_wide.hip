@@ -462,6 +462,459 @@ int32_t launch_fwd_wide_nt(const MhaArgs& a, hipStream_t s) {
     return VIPANT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------- backward
+// Single pass, streamed operands (the scaffolding of mha_bwd1s_kernel in attention.hip: persistent workgroup, Q / dO rows through a
+// four-stage ring, two K images, per-step delta, everything requested as LDS-DMA pieces three steps ahead), with the five
+// contractions on v_mfma_f32_32x32x16_bf16.  Key on the MFMA column, 32-key blocks:
+//     S = Q K^T, dP = dO V^T - delta      (A = the step's Q / dO rows, B = the block's K / V rows; rows = queries in registers)
+//     dV^T += dO^T P, dK^T += Q^T dS      (the packed accumulators ARE the B operands; A = transposed reads of the step's rows)
+//     dQ^T += K^T dS^T                    (sums over keys = lanes: dS crosses LDS once, [key][32 queries] bf16)
+// Ten key blocks do not split over four waves: waves 0, 1 take three (192 accumulator registers), waves 2, 3 take two and the dQ^T
+// product of the previous step, one 32-row d tile each (20 MFMAs against 16 per key block; their K^T fragments stay in registers).
+// Per score the VALU work is what it was (scale, exp, multiply, two packs); beside a 32x32x16 MFMA four to five of those
+// instructions issue for free instead of one.
+struct BwdProb { const bf16_t* q; const bf16_t* dO; const bf16_t* o; const float* lse; uint32_t limq, limdo; uint32_t any; };
+
+template <int NB, bool HAS_DQ>
+__device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, const int wave, const int lane0, const int kb0) {
+    constexpr int SP = 320, NU = 10, KIMG = SP * 128, XB = SP * 64, STG = 8192;
+    char* const xbuf = smem + 2 * KIMG;
+    char* const ring = xbuf + 2 * XB;
+    float* const sdel = (float*)(ring + 4 * STG);      // [2][32]
+    char* const obuf = ring + 4 * STG + 256;           // [4 waves][8 rows x 128 B]
+    char* const lbuf = obuf + 4096;                    // [4 waves][64 floats]
+    const int D = p.H * 64, ld = 3 * D;
+    const int nprob = p.batch * p.H;
+    const int dtl = wave & 1;                          // the d tile of a light wave's dQ^T product
+
+    auto make_prob = [&](int pr) {
+        BwdProb t;
+        t.any = pr < nprob ? 1u : 0u;
+        const int pq = t.any ? pr : 0;
+        const int b = pq / p.H, h = pq % p.H;
+        t.q = p.qkv + (int64_t)b * p.S * ld + h * 64;
+        t.dO = p.dout + (int64_t)b * p.S * D + h * 64;
+        t.o = p.out + (int64_t)b * p.S * D + h * 64;
+        t.lse = p.lse + (int64_t)pq * p.S;
+        const int64_t rq = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2, rd = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
+        t.limq = t.any ? (uint32_t)(rq > 0xFFFFFFFFll ? 0xFFFFFFFFll : rq) : 0u;
+        t.limdo = t.any ? (uint32_t)(rd > 0xFFFFFFFFll ? 0xFFFFFFFFll : rd) : 0u;
+        return t;
+    };
+    // per-lane constants of the requests (the swizzle of an 8-row block depends on the block's parity; the blocks this wave brings
+    // -- 4 i + wave of an image, block wave of a stage -- all have parity wave & 1)
+    struct LaneK { uint32_t vq, vdo, vo, vl; };
+    auto make_lanek = [&](int lane) {
+        LaneK k;
+        const int r8 = lane >> 3, c = (lane & 7) ^ img32_swz((wave & 1) * 8 + r8);
+        k.vq = (uint32_t)(r8 * (ld * 2) + c * 16);
+        k.vdo = (uint32_t)(r8 * (D * 2) + c * 16);
+        k.vo = (uint32_t)(r8 * (D * 2) + (lane & 7) * 16);
+        k.vl = (uint32_t)(lane * 4);
+        return k;
+    };
+    auto stage_pieces = [&](const BwdProb& t, int v, int slot, const LaneK& k) {
+        char* st = ring + slot * STG;
+        lds_dma16_asm(uniform_rsrc(t.q, t.limq), st + wave * 1024, k.vq, (uint32_t)((32 * v + 8 * wave) * (ld * 2)));
+        lds_dma16_asm(uniform_rsrc(t.dO, t.limdo), st + 4096 + wave * 1024, k.vdo, (uint32_t)((32 * v + 8 * wave) * (D * 2)));
+    };
+    auto k_piece = [&](const BwdProb& t, int i, char* img, const LaneK& k) {
+        const int blk = 4 * i + wave;
+        lds_dma16_asm(uniform_rsrc(t.q, t.limq), img + blk * 1024, k.vq, (uint32_t)(blk * 8 * (ld * 2) + D * 2));
+    };
+    auto o_piece = [&](const BwdProb& t, int v, const LaneK& k) {
+        lds_dma16_asm(uniform_rsrc(t.o, t.any ? (uint32_t)(((int64_t)(p.S - 1) * D + 64) * 2) : 0u), obuf + wave * 1024, k.vo,
+                      (uint32_t)((32 * v + 8 * wave) * (D * 2)));
+    };
+    auto lse_piece = [&](const BwdProb& t, int v, const LaneK& k) {
+        lds_dma4_asm(uniform_rsrc(t.lse, t.any ? (uint32_t)p.S * 4u : 0u), lbuf + wave * 256, k.vl, (uint32_t)(v * 128));
+    };
+    auto delta_step = [&](int slot, int dbuf, int lane) {
+        const int row = wave * 8 + (lane >> 3), c0 = lane & 7;
+        const v4i32_t dw = *(const v4i32_t*)(ring + slot * STG + 4096 + row * 128 + ((c0 ^ img32_swz(row)) << 4));
+        const v4i32_t ow = *(const v4i32_t*)(obuf + wave * 1024 + lane * 16);
+        const bf16x8 d0 = __builtin_bit_cast(bf16x8, dw), o0 = __builtin_bit_cast(bf16x8, ow);
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc += (float)d0[e] * (float)o0[e];
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xF, 0xF, true));
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xF, 0xF, true));
+        sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xF, 0xF, true));
+        if (c0 == 0) sdel[dbuf * 32 + row] = sacc;
+    };
+    // The V rows travel like the K rows: as an image, one piece per step, into the K image this problem no longer reads (its K / K^T
+    // fragments are taken into registers at the problem switch); the next problem takes its V fragments from there.  (Loading them
+    // straight into registers with inline asm -- the wait comes a problem later -- is not safe: with every register in use the
+    // allocator moves a "loaded" fragment before its data has arrived.)
+    auto v_piece = [&](const BwdProb& t, int i, char* img, const LaneK& k) {
+        const int blk = 4 * i + wave;
+        lds_dma16_asm(uniform_rsrc(t.q, t.limq), img + blk * 1024, k.vq, (uint32_t)(blk * 8 * (ld * 2) + 2 * D * 2));
+    };
+
+    // ---- preamble: the first problem's K image, its first three stages, its V fragments, lse of step 0, O of steps 0 and 1
+    int prob = blockIdx.x;
+    int gs = 0, cur = 0;
+    BwdProb pc = make_prob(prob);
+    {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const LaneK lk = make_lanek(lane);
+        for (int i = 0; i < 10; ++i) k_piece(pc, i, smem, lk);
+        for (int i = 0; i < 10; ++i) v_piece(pc, i, smem + KIMG, lk);
+        stage_pieces(pc, 0, 0, lk);
+        stage_pieces(pc, 1, 1, lk);
+        stage_pieces(pc, 2, 2, lk);
+        lse_piece(pc, 0, lk);
+        o_piece(pc, 0, lk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        delta_step(0, 0, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        o_piece(pc, 1, lk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    for (; prob < nprob; prob += gridDim.x, cur ^= 1) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int tid = wave * 64 + lane;
+        const int r = lane & 31, hh = lane >> 5;
+        const LaneK lk = make_lanek(lane);
+        const BwdProb pn = make_prob(prob + gridDim.x);
+        char* const kimg = smem + cur * KIMG;
+        char* const knext = smem + (cur ^ 1) * KIMG;
+
+        // ---- problem switch: the K image landed during the previous problem
+        for (int i = p.S * 8 + tid; i < SP * 8; i += 256) *(u32x4*)(kimg + i * 16) = u32x4{0u, 0u, 0u, 0u};      // keys >= S
+        __syncthreads();                               // ... and delta of step 0 is visible
+        // per-lane LDS offsets: row fragment (row r, d = 16 s + 8 hh ..) and transposed fragment (see the forward)
+        uint32_t ka[4], va[2][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ka[s] = (uint32_t)(r * 128 + (((2 * s + hh) ^ img32_swz(r)) << 4));
+        const int q4 = (lane >> 2) & 3, pp = lane & 3, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int rl = 8 * jj + 4 * hh + q4;
+                va[dt][jj] = (uint32_t)(rl * 128 + (((dt * 4 + 2 * gsel + (pp >> 1)) ^ img32_swz(rl)) << 4) + (pp & 1) * 8);
+            }
+        // K and V rows of this wave's key blocks as B-operand fragments, resident; keys >= S: zero K rows, finite V rows
+        bf16x8 kf[NB][4], vf[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kf[j][s] = *(const bf16x8*)(kimg + (kb0 + j) * 4096 + ka[s]);
+                vf[j][s] = *(const bf16x8*)(knext + (kb0 + j) * 4096 + ka[s]);
+            }
+        // light waves: K^T of their d tile for all 20 key steps (A operand of the dQ^T product: row d = 32 dtl + r, k-slot j of lane
+        // half hh = key 16 s + 8 hh + j), resident
+        constexpr int NKT = HAS_DQ ? 20 : 1;
+        bf16x8 kT[NKT];
+        if (HAS_DQ) {
+#pragma unroll
+            for (int s = 0; s < NKT; ++s) {
+                bf16x4 part[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int rl = 8 * hh + 4 * jj + q4;                      // key row inside the 16-key step (the swizzle sees only this)
+                    part[jj] = lds_read_tr16(kimg + s * 2048 + rl * 128 + (((dtl * 4 + 2 * gsel + (pp >> 1)) ^ img32_swz(rl)) << 4) + (pp & 1) * 8);
+                }
+                bf16x8 v;
+                v[0] = part[0][0]; v[1] = part[0][1]; v[2] = part[0][2]; v[3] = part[0][3];
+                v[4] = part[1][0]; v[5] = part[1][1]; v[6] = part[1][2]; v[7] = part[1][3];
+                kT[s] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { settle_a(kf[j][s]); settle_a(vf[j][s]); }
+        if (HAS_DQ) {
+#pragma unroll
+            for (int s = 0; s < NKT; ++s) settle_a(kT[s]);
+        }
+        __builtin_amdgcn_s_barrier();                  // both images are in registers everywhere: the next problem's pieces may land
+
+        bf16_t* const dq_base = p.dqkv + (pc.q - p.qkv);
+        const __amdgpu_buffer_rsrc_t rs_dq = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 64) * 2));
+        // exchange buffer X[key][32 queries] bf16, 64-byte rows, the 8-byte slot index XOR-ed with (key >> 2) & 7.  Write: this
+        // lane's key row, slot of query group g' (queries 8 g' + 4 hh ..) = 2 g' + hh.
+        const uint32_t fxw = (uint32_t)((r >> 2) & 7);
+        uint32_t xwo[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) xwo[gq] = (uint32_t)((kb0 * 32 + r) * 64) + ((((uint32_t)(2 * gq + hh)) ^ fxw) << 3);
+        // Read (light waves; B operand: k-slot j of lane half hh = key 16 s + 8 hh + j, column = query r): transposed reads of rows
+        // 16 s + 8 hh + 4 jj + q4, slot 4 gsel + pp; the row's XOR term is (4 (s & 1) + 2 hh + jj)
+        uint32_t xro[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+                xro[jj][sp] = (uint32_t)((8 * hh + 4 * jj + q4) * 64) + ((((uint32_t)(4 * gsel + pp)) ^ (uint32_t)(4 * sp + 2 * hh + jj)) << 3);
+
+        f32x16 dkT[NB][2], dvT[NB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { dkT[j][dt] = zero16(); dvT[j][dt] = zero16(); }
+
+        // row constants of a step, per accumulator register i <-> query (i & 3) + 8 (i >> 2) + 4 hh: -lse * log2e (queries >= S:
+        // -inf) and -delta
+        f32x16 nl, ndl;
+        auto make_stats = [&](int u, int dbuf) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 lv = *(const f32x4*)(lbuf + wave * 256 + (8 * gq + 4 * hh) * 4);
+                const f32x4 dv4 = *(const f32x4*)(sdel + dbuf * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    nl[4 * gq + e] = u * 32 + 8 * gq + 4 * hh + e < p.S ? -lv[e] * LOG2E : -INFINITY;
+                    ndl[4 * gq + e] = -dv4[e];
+                }
+            }
+        };
+        make_stats(0, gs & 1);
+
+        f32x16 dqa = zero16();
+        for (int u = 0; u < NU; ++u, ++gs) {
+            const char* st = ring + (gs & 3) * STG;
+            char* const xw = xbuf + (u & 1) * XB;
+            const char* const xr = xbuf + ((u & 1) ^ 1) * XB;         // X of step u - 1
+            const BwdProb& pr1 = u + 1 < NU ? pc : pn; const int v1 = u + 1 < NU ? u + 1 : u + 1 - NU;
+            const BwdProb& pr2 = u + 2 < NU ? pc : pn; const int v2 = u + 2 < NU ? u + 2 : u + 2 - NU;
+            const BwdProb& pr3 = u + 3 < NU ? pc : pn; const int v3 = u + 3 < NU ? u + 3 : u + 3 - NU;
+            // delta of the NEXT step; then this step's requests, oldest first: lse of the next step, O of the step after next,
+            // [three image pieces], [the dQ stores]
+            delta_step((gs + 1) & 3, (gs + 1) & 1, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lse_piece(pr1, v1, lk);
+            o_piece(pr2, v2, lk);
+            // this step's operand fragments
+            bf16x8 qrow[4], drow[4], qT[2][2], dT[2][2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qrow[s] = *(const bf16x8*)(st + ka[s]);
+                drow[s] = *(const bf16x8*)(st + 4096 + ka[s]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x4 qlo = lds_read_tr16(st + va[dt][0] + s2 * 2048), qhi = lds_read_tr16(st + va[dt][1] + s2 * 2048);
+                    const bf16x4 dlo = lds_read_tr16(st + 4096 + va[dt][0] + s2 * 2048), dhi = lds_read_tr16(st + 4096 + va[dt][1] + s2 * 2048);
+                    bf16x8 a, b;
+                    a[0] = qlo[0]; a[1] = qlo[1]; a[2] = qlo[2]; a[3] = qlo[3]; a[4] = qhi[0]; a[5] = qhi[1]; a[6] = qhi[2]; a[7] = qhi[3];
+                    b[0] = dlo[0]; b[1] = dlo[1]; b[2] = dlo[2]; b[3] = dlo[3]; b[4] = dhi[0]; b[5] = dhi[1]; b[6] = dhi[2]; b[7] = dhi[3];
+                    qT[dt][s2] = a; dT[dt][s2] = b;
+                }
+            stage_pieces(pr3, v3, (gs + 3) & 3, lk);
+            k_piece(pn, u, knext, lk);
+            v_piece(pn, u, kimg, lk);
+
+            // ---- the key blocks, software-pipelined: region j = { S / dP of block j + 1, dV / dK of block j - 1 } beside the
+            // arithmetic of block j
+            f32x16 sa[2], dp[2];
+            bf16x8 pf[2][2], dsf[2][2];               // [parity of the block][k-step]
+            auto qk = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, par = j & 1;
+                sa[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow[0], kf[j][0], zero16(), 0, 0, 0);
+                dp[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow[0], vf[j][0], ndl, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) {
+                    sa[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow[s], kf[j][s], sa[par], 0, 0, 0);
+                    dp[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow[s], vf[j][s], dp[par], 0, 0, 0);
+                }
+            };
+            auto arith = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, par = j & 1;
+                f32x16 pe, de;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    pe[i] = __builtin_amdgcn_exp2f(sa[par][i] * C2 + nl[i]);
+                    de[i] = pe[i] * dp[par][i];        // dp already holds dP - delta; the 1/sqrt(d) factor goes to dq / dk
+                }
+                pf[par][0] = pack8f(pe[0], pe[1], pe[2], pe[3], pe[4], pe[5], pe[6], pe[7]);
+                pf[par][1] = pack8f(pe[8], pe[9], pe[10], pe[11], pe[12], pe[13], pe[14], pe[15]);
+                dsf[par][0] = pack8f(de[0], de[1], de[2], de[3], de[4], de[5], de[6], de[7]);
+                dsf[par][1] = pack8f(de[8], de[9], de[10], de[11], de[12], de[13], de[14], de[15]);
+                // dS to the exchange buffer: group g' = 2 s' + jj is dwords 2 jj, 2 jj + 1 of k-step s'
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const u32x4 dw = __builtin_bit_cast(u32x4, dsf[par][s2]);
+                    *(u32x2*)(xw + j * 2048 + xwo[2 * s2]) = u32x2{dw[0], dw[1]};
+                    *(u32x2*)(xw + j * 2048 + xwo[2 * s2 + 1]) = u32x2{dw[2], dw[3]};
+                }
+            };
+            auto dvdk = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, par = j & 1;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dvT[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dT[dt][s2], pf[par][s2], dvT[j][dt], 0, 0, 0);
+                        dkT[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[dt][s2], dsf[par][s2], dkT[j][dt], 0, 0, 0);
+                    }
+            };
+            // light waves: dQ^T of the previous step, 20 key steps in NB + 1 slices
+            auto dq_slice = [&](auto jc) {
+                if (HAS_DQ) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int s0 = j * 20 / (NB + 1), s1 = (j + 1) * 20 / (NB + 1);
+#pragma unroll
+                    for (int s = s0; s < s1; ++s) {
+                        const bf16x4 lo = lds_read_tr16(xr + s * 1024 + xro[0][s & 1]), hi = lds_read_tr16(xr + s * 1024 + xro[1][s & 1]);
+                        bf16x8 xf;
+                        xf[0] = lo[0]; xf[1] = lo[1]; xf[2] = lo[2]; xf[3] = lo[3]; xf[4] = hi[0]; xf[5] = hi[1]; xf[6] = hi[2]; xf[7] = hi[3];
+                        dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s], xf, dqa, 0, 0, 0);
+                    }
+                }
+            };
+            if (HAS_DQ) dqa = zero16();
+            qk(Int2<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // region 0
+            if (NB > 1) qk(Int2<1>{});
+            arith(Int2<0>{});
+            dq_slice(Int2<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // region 1
+            if (NB > 2) qk(Int2<(NB > 2 ? 2 : 0)>{});
+            dvdk(Int2<0>{});
+            arith(Int2<1>{});
+            dq_slice(Int2<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // region 2
+            dvdk(Int2<1>{});
+            if (NB > 2) arith(Int2<(NB > 2 ? 2 : 0)>{});
+            dq_slice(Int2<2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (NB > 2) {
+                dvdk(Int2<(NB > 2 ? 2 : 0)>{});
+                dq_slice(Int2<3>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (HAS_DQ) {
+                // dQ rows of step u - 1 (rows >= S and the step before the first: out of the descriptor's range, dropped)
+                const int q = (u - 1) * 32 + r;
+#pragma unroll
+                for (int G = 0; G < 2; ++G) {
+                    uint32_t w[2][2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int i0 = 4 * (2 * G + gg);
+                        const bf16x4 v = f32x4_to_bf16x4(f32x4{dqa[i0] * SCALE, dqa[i0 + 1] * SCALE, dqa[i0 + 2] * SCALE, dqa[i0 + 3] * SCALE});
+                        const u32x2 t = __builtin_bit_cast(u32x2, v);
+                        w[gg][0] = t[0]; w[gg][1] = t[1];
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    const uint32_t off = (u > 0 && q < p.S) ? (uint32_t)(((int64_t)q * ld + 32 * dtl + 16 * G + 8 * hh) * 2) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]}, rs_dq, off, 0, 0);
+                }
+            }
+            // everything but this step's four pieces and (light waves) two stores: the lse words, the O rows, every older piece
+            if (HAS_DQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            make_stats(v1, (gs + 1) & 1);
+        }
+        int nst = 0;
+        if (HAS_DQ) {
+            // dQ^T of the last step
+            const char* const xr = xbuf + ((NU - 1) & 1) * XB;
+            dqa = zero16();
+#pragma unroll
+            for (int s = 0; s < 20; ++s) {
+                const bf16x4 lo = lds_read_tr16(xr + s * 1024 + xro[0][s & 1]), hi = lds_read_tr16(xr + s * 1024 + xro[1][s & 1]);
+                bf16x8 xf;
+                xf[0] = lo[0]; xf[1] = lo[1]; xf[2] = lo[2]; xf[3] = lo[3]; xf[4] = hi[0]; xf[5] = hi[1]; xf[6] = hi[2]; xf[7] = hi[3];
+                dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s], xf, dqa, 0, 0, 0);
+            }
+            const int q = (NU - 1) * 32 + r;
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {
+                uint32_t w[2][2];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int i0 = 4 * (2 * G + gg);
+                    const bf16x4 v = f32x4_to_bf16x4(f32x4{dqa[i0] * SCALE, dqa[i0 + 1] * SCALE, dqa[i0 + 2] * SCALE, dqa[i0 + 3] * SCALE});
+                    const u32x2 t = __builtin_bit_cast(u32x2, v);
+                    w[gg][0] = t[0]; w[gg][1] = t[1];
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                const uint32_t off = q < p.S ? (uint32_t)(((int64_t)q * ld + 32 * dtl + 16 * G + 8 * hh) * 2) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]}, rs_dq, off, 0, 0);
+            }
+            nst += 2;
+        }
+        // dK / dV: lane = key, registers = d; the same pairing of the two lane halves into 16-byte pieces (rows >= S dropped)
+        {
+            const __amdgpu_buffer_rsrc_t rs_dkv = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 2 * D + 64) * 2));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int key = (kb0 + j) * 32 + r;
+#pragma unroll
+                for (int which = 0; which < 2; ++which)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const f32x16& a = which ? dvT[j][dt] : dkT[j][dt];
+                        const float sc = which ? 1.0f : SCALE;
+#pragma unroll
+                        for (int G = 0; G < 2; ++G) {
+                            uint32_t w[2][2];
+#pragma unroll
+                            for (int gg = 0; gg < 2; ++gg) {
+                                const int i0 = 4 * (2 * G + gg);
+                                const bf16x4 v = f32x4_to_bf16x4(f32x4{a[i0] * sc, a[i0 + 1] * sc, a[i0 + 2] * sc, a[i0 + 3] * sc});
+                                const u32x2 t = __builtin_bit_cast(u32x2, v);
+                                w[gg][0] = t[0]; w[gg][1] = t[1];
+                            }
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                            const uint32_t off = key < p.S ? (uint32_t)(((int64_t)key * ld + (1 + which) * D + 32 * dt + 16 * G + 8 * hh) * 2) : 0xFFFFFFF0u;
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]}, rs_dkv, off, 0, 0);
+                        }
+                    }
+            }
+        }
+        // every piece went out before this problem's last stores: 8 NB (+ 2 on the light waves)
+        if (HAS_DQ) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NB + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NB) : "memory");
+        (void)nst;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave is done with this K image and with X
+        pc = pn;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mha_bwd_wide_kernel(MhaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 2) bwd_wide_body<3, false>(p, smem, wave, lane0, 3 * wave);
+    else bwd_wide_body<2, true>(p, smem, wave, lane0, 6 + 2 * (wave - 2));
+}
+
+int32_t launch_bwd_wide_impl(const MhaArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * 320 * 128 + 2 * 320 * 64 + 4 * 8192 + 256 + 4096 + 1024;
+    static bool configured = false;
+    static int cus = 0;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        VIPANT_HIP_TRY(hipGetDevice(&dev));
+        VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        configured = true;
+    }
+    const int nprob = a.batch * a.H;
+    hipLaunchKernelGGL(mha_bwd_wide_kernel, dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
 }  // namespace
 
 namespace vipant_attn {
@@ -469,6 +922,11 @@ namespace vipant_attn {
 int32_t launch_fwd_wide(const MhaArgs& a, hipStream_t s) {
     VIPANT_REQUIRE(a.S > 288 && a.S <= 320, VIPANT_EBADSHAPE, "mha (wide forward): 288 < S <= 320 expected, got %d", a.S);
     return launch_fwd_wide_nt<10>(a, s);
+}
+
+int32_t launch_bwd_wide(const MhaArgs& a, hipStream_t s) {
+    VIPANT_REQUIRE(a.S > 288 && a.S <= 320, VIPANT_EBADSHAPE, "mha (wide backward): 288 < S <= 320 expected, got %d", a.S);
+    return launch_bwd_wide_impl(a, s);
 }
 
 }  // namespace vipant_attn

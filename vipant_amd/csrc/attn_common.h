@@ -25,9 +25,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base,
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return make_rsrc((const void*)(((uint64_t)hi << 32) | lo), (uint32_t)__builtin_amdgcn_readfirstlane(bytes));
 }
+// LDS-DMA through inline asm: invisible to hipcc's wait insertion.  (With a builtin piece in flight every transposed-read builtin --
+// no memory operand: "may alias" -- gets an s_waitcnt vmcnt(0) in front; inside a loop that streams its operands that is an HBM
+// round trip per region.)  The caller owns the vmcnt wait and the barrier that publish the bytes.  M0 carries the LDS base.
+__device__ __forceinline__ void lds_dma16_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
+}
+
+__device__ __forceinline__ void lds_dma4_asm(__amdgpu_buffer_rsrc_t rs, const void* lds_base, uint32_t voff, uint32_t soff) {
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(lds_base));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(la), "v"(voff), "s"(rs), "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)soff)) : "memory", "m0");
+}
+
 #endif
 
 // attention_wide.hip: forward on v_mfma_f32_32x32x16_bf16 for 288 < S <= 320, no mask (the audio tower's shape)
 int32_t launch_fwd_wide(const MhaArgs& a, hipStream_t s);
+// ... and the single-pass backward on the same MFMA shape (streamed operands, as mha_bwd1s_kernel of attention.hip)
+int32_t launch_bwd_wide(const MhaArgs& a, hipStream_t s);
 
 }  // namespace vipant_attn
