@@ -72,7 +72,7 @@ def parse():
                          "framework's default)")
     ap.add_argument("--full-last-block", action="store_true",
                     help="running.last_block_rows=False: evaluate the towers' last block on every token, as the reference does before "
-                         "its read-out discards all rows but one (default: on the read-out rows only -- exact, see DESIGN.md)")
+                         "its read-out discards all rows but one (default: on the read-out rows only -- exact up to rounding order, see DESIGN.md)")
     ap.add_argument("--no-full-last-block-check", action="store_true",
                     help="skip the 8 extra steps that report the step time with the full last block beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,7 +260,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
                                   "NOT the headline configuration",
                       "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}", "negatives": "local",
                       "recompute_mlp": bool(args.recompute_mlp), "micro_batch": int(args.micro_batch), "fp8_gemm": bool(args.fp8),
-                      "last_block": "read-out rows only (exact)" if lbr else "every token"},
+                      "last_block": "read-out rows only (exact up to bf16 rounding order)" if lbr else "every token"},
            "loss": round(float(loss.detach()), 4), "step_tflops": round(algo_flops / (ms * 1e-3) / 1e12, 1),
            "step_mfma_frac": round(algo_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
@@ -381,7 +381,7 @@ def main():
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",
                    "negatives": "global (all-gather)" if world > 1 else "global",
                    # every feature and gradient is what the full block gives; --full-last-block computes the discarded rows too
-                   "last_block": "read-out rows only (exact dead-row elimination)" if lbr else "every token"},
+                   "last_block": "read-out rows only (dead-row elimination: exact up to bf16 rounding order)" if lbr else "every token"},
         "loss": round(float(loss.detach()), 4),
         "step_tflops": round(step_flops / (ms * 1e-3) / 1e12, 1),
         "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

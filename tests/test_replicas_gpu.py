@@ -171,7 +171,8 @@ def _run_at_local(rank, world, port, out):
         from vipant_amd.config import compose
         from vipant_amd.module import adjust_learning_rate
         from vipant_amd.monitor import VALMonitor
-        cfg = compose(AT_OV + ([f"seed={os.environ['VIPANT_TEST_SEED']}"] if os.environ.get("VIPANT_TEST_SEED") else []))
+        cfg = compose(AT_OV + ([f"seed={os.environ['VIPANT_TEST_SEED']}"] if os.environ.get("VIPANT_TEST_SEED") else [])
+                      + [f"running.last_block_rows={os.environ.get('VIPANT_TEST_LAST_ROWS', 'True')}"])
         cfg.rank = rank                              # the synthetic loader seeds per rank: every replica has its own batch
         torch.cuda.set_device(0)
         torch.manual_seed(cfg.seed)
@@ -190,12 +191,14 @@ def _run_at_local(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path):
+@pytest.mark.parametrize("rows", [True, False], ids=["rows", "fullblock"])
+def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path, monkeypatch, rows):
     """cfg3 product path (VALMonitor.step, `running.negatives=local`) on two replicas against the CPU oracle taking one
     LARS step on  mean_r InfoNCE(audio_r, text_r).  Biases, LayerNorm parameters and logit_scale have no trust ratio
     (lars.py:58-66), so a SUM-instead-of-mean reduction or a per-replica LR would show as a factor `world` in their update."""
     from oracle import ref_cpu as R
     out = str(tmp_path / "at")
+    monkeypatch.setenv("VIPANT_TEST_LAST_ROWS", str(rows))
     mp.spawn(_run_at_local, args=(2, _free_port(), out), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     for k in r0["after"]:                            # replicas stay in lock-step
@@ -239,7 +242,9 @@ def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path):
     # `running.last_block_rows` (this seed: 0.044 / 0.066, the noisiest of the six in both modes); the noisiest tensor
     # (near-cancelling LayerNorm-weight / bias gradients) 0.08 ... 0.23
     print("update-direction error vs the fp32 oracle: median %.4f max %.4f" % (dirs[len(dirs) // 2], dirs[-1]))
-    assert dirs[len(dirs) // 2] < 8e-2 and dirs[-1] < 0.3, (dirs[len(dirs) // 2], dirs[-1])
+    # the full last block keeps the round-2 budget; the read-out-row path (exact up to rounding: dh + dq rows are rounded to bf16
+    # twice) has its own, 1.2x its worst observed seed
+    assert dirs[len(dirs) // 2] < (8e-2 if rows else 5e-2) and dirs[-1] < 0.3, (rows, dirs[len(dirs) // 2], dirs[-1])
 
 
 @pytest.mark.timeout(900)

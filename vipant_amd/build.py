@@ -84,10 +84,29 @@ def stale() -> bool:
     return _older(LIB, sources() + _headers())
 
 
+def _probe_flags():
+    """`-mllvm -amdgpu-mfma-vgpr-form` is an internal LLVM option: on a toolchain without it every attention file would fail with
+    'Unknown command line argument'.  Probe once; without the option the files still build (the 512-register kernels then get
+    AGPR-destination MFMAs and run slower; the no-spill test still guards them)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "p.hip")
+        with open(src, "w") as f:
+            f.write("__global__ void k() {}\n")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src, "-o", os.path.join(d, "p.o")],
+                           stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        print("[vipant_amd.build] WARNING: this hipcc does not know -mllvm -amdgpu-mfma-vgpr-form; building the attention kernels "
+              "without it (slower single-pass backward)", flush=True)
+        for k, v in EXTRA_CFLAGS.items():
+            EXTRA_CFLAGS[k] = [a for i, a in enumerate(v) if a != "-amdgpu-mfma-vgpr-form" and not (a == "-mllvm" and i + 1 < len(v) and v[i + 1] == "-amdgpu-mfma-vgpr-form")]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    _probe_flags()
     hdrs = _headers()
     todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs) or not os.path.exists(_obj(s)[:-2] + ".resources.json")]
 

@@ -1658,10 +1658,11 @@ int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
     // LDS-instruction bound, more waves only add contention); backward is faster with 8
     const bool tight = a.S > (NT - 2) * 16;
     if constexpr (NT == 20 && !CAUSAL) {
-        // round 4: the audio tower's shape (288 < S <= 320) on v_mfma_f32_32x32x16_bf16 (attention_wide.hip); VIPANT_ATTN_FWD=16 keeps
-        // the 16x16x32 kernel of this file for A/B timing
-        static const int variant = attn_env("VIPANT_ATTN_FWD", 32);
-        if (variant != 16 && a.S > 288) return launch_fwd_wide(a, s);
+        // round 4: VIPANT_ATTN_FWD=32 takes the audio tower's shape (288 < S <= 320) through the v_mfma_f32_32x32x16_bf16 kernel of
+        // attention_wide.hip (persistent, two image sets, software-pipelined): built, bit-for-bit as accurate, and measured equal to
+        // this file's 16x16x32 kernel (299-309 vs 297-307 us at b = 512), which therefore stays the default
+        static const int variant = attn_env("VIPANT_ATTN_FWD", 16);
+        if (variant == 32 && a.S > 288) return launch_fwd_wide(a, s);
     }
     return tight ? launch_fwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_fwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }

@@ -95,7 +95,7 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 #ifdef VIPANT_ATTN_STAMPS
-__device__ unsigned long long g_attnw_stamps[64];
+__device__ unsigned long long g_attnw_stamps[128];
 #define STAMP(i) do { if (prob == 3000 && lane == 0 && wave == 1) g_attnw_stamps[i] = __builtin_readcyclecounter(); } while (0)
 // per-workgroup trace: {hw id | xcc id << 32, realtime at start, at "second key half landed", at end} (100 MHz ticks)
 __device__ unsigned long long g_attnw_trace[8192 * 4];
@@ -104,6 +104,12 @@ __device__ unsigned long long g_attnw_trace[8192 * 4];
              : __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TRACE(k) do {} while (0)
+#endif
+#ifdef VIPANT_ATTN_STAMPS
+// backward: waves 1 (three key blocks) and 3 (two key blocks + dQ) of problem 3000, 32 stamps each
+#define BSTAMP(i) do { if (prob == 3000 && lane == 0 && (wave & 1)) g_attnw_stamps[64 + 32 * (wave >> 1) + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BSTAMP(i) do {} while (0)
 #define STAMP(i) do {} while (0)
 #endif
 
@@ -463,6 +469,14 @@ int32_t launch_fwd_wide_nt(const MhaArgs& a, hipStream_t s) {
 }
 
 
+// An MFMA whose accumulator lives in the ACCUMULATOR half of the register file, through inline asm.  The file is compiled with
+// -amdgpu-mfma-vgpr-form (the scores must land where the VALU reads them); with that flag hipcc also gives the long-lived dK / dV
+// accumulators VGPR-form MFMAs and, since 192 of them do not fit beside the working set, copies each one out of and back into the
+// accumulator file around every update (400 v_accvgpr moves per step).  A and B operands: VGPRs.
+__device__ __forceinline__ void mfma_acc_a(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 // ------------------------------------------------------------------------------------------- backward
 // Single pass, streamed operands (the scaffolding of mha_bwd1s_kernel in attention.hip: persistent workgroup, Q / dO rows through a
 // four-stage ring, two K images, per-step delta, everything requested as LDS-DMA pieces three steps ahead), with the five
@@ -541,7 +555,7 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
         sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xF, 0xF, true));
         sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xF, 0xF, true));
         sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xF, 0xF, true));
-        if (c0 == 0) sdel[dbuf * 32 + row] = sacc;
+        if (c0 == 0) sdel[dbuf * 32 + row] = -sacc;     // the consumer wants -delta (initial accumulator of dP)
     };
     // The V rows travel like the K rows: as an image, one piece per step, into the K image this problem no longer reads (its K / K^T
     // fragments are taken into registers at the problem switch); the next problem takes its V fragments from there.  (Loading them
@@ -585,6 +599,7 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
         char* const kimg = smem + cur * KIMG;
         char* const knext = smem + (cur ^ 1) * KIMG;
 
+        BSTAMP(0);
         // ---- problem switch: the K image landed during the previous problem
         for (int i = p.S * 8 + tid; i < SP * 8; i += 256) *(u32x4*)(kimg + i * 16) = u32x4{0u, 0u, 0u, 0u};      // keys >= S
         __syncthreads();                               // ... and delta of step 0 is visible
@@ -671,14 +686,21 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                 const f32x4 dv4 = *(const f32x4*)(sdel + dbuf * 32 + 8 * gq + 4 * hh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    nl[4 * gq + e] = u * 32 + 8 * gq + 4 * hh + e < p.S ? -lv[e] * LOG2E : -INFINITY;
-                    ndl[4 * gq + e] = -dv4[e];
+                    nl[4 * gq + e] = -lv[e] * LOG2E;
+                    ndl[4 * gq + e] = dv4[e];
                 }
+            }
+            if (u == NU - 1) {                         // queries >= S exist in the last step only (S > 288)
+                const int qlim = p.S - u * 32 - 4 * hh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (8 * (i >> 2) + (i & 3) >= qlim) nl[i] = -INFINITY;
             }
         };
         make_stats(0, gs & 1);
 
         f32x16 dqa = zero16();
+        BSTAMP(1);
         for (int u = 0; u < NU; ++u, ++gs) {
             const char* st = ring + (gs & 3) * STG;
             char* const xw = xbuf + (u & 1) * XB;
@@ -713,6 +735,7 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
             stage_pieces(pr3, v3, (gs + 3) & 3, lk);
             k_piece(pn, u, knext, lk);
             v_piece(pn, u, kimg, lk);
+            if (u == 5) BSTAMP(20);
 
             // ---- the key blocks, software-pipelined: region j = { S / dP of block j + 1, dV / dK of block j - 1 } beside the
             // arithmetic of block j
@@ -754,8 +777,8 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        dvT[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dT[dt][s2], pf[par][s2], dvT[j][dt], 0, 0, 0);
-                        dkT[j][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[dt][s2], dsf[par][s2], dkT[j][dt], 0, 0, 0);
+                        mfma_acc_a(dvT[j][dt], dT[dt][s2], pf[par][s2]);
+                        mfma_acc_a(dkT[j][dt], qT[dt][s2], dsf[par][s2]);
                     }
             };
             // light waves: dQ^T of the previous step, 20 key steps in NB + 1 slices
@@ -763,13 +786,18 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                 if (HAS_DQ) {
                     constexpr int j = decltype(jc)::value;
                     constexpr int s0 = j * 20 / (NB + 1), s1 = (j + 1) * 20 / (NB + 1);
+                    // all of the slice's fragments are requested before the first MFMA (a read per MFMA, awaited on the spot, exposes the
+                    // LDS latency twenty times per step)
+                    bf16x8 xf[s1 - s0];
 #pragma unroll
                     for (int s = s0; s < s1; ++s) {
                         const bf16x4 lo = lds_read_tr16(xr + s * 1024 + xro[0][s & 1]), hi = lds_read_tr16(xr + s * 1024 + xro[1][s & 1]);
-                        bf16x8 xf;
-                        xf[0] = lo[0]; xf[1] = lo[1]; xf[2] = lo[2]; xf[3] = lo[3]; xf[4] = hi[0]; xf[5] = hi[1]; xf[6] = hi[2]; xf[7] = hi[3];
-                        dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s], xf, dqa, 0, 0, 0);
+                        bf16x8 t;
+                        t[0] = lo[0]; t[1] = lo[1]; t[2] = lo[2]; t[3] = lo[3]; t[4] = hi[0]; t[5] = hi[1]; t[6] = hi[2]; t[7] = hi[3];
+                        xf[s - s0] = t;
                     }
+#pragma unroll
+                    for (int s = s0; s < s1; ++s) dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[s], xf[s - s0], dqa, 0, 0, 0);
                 }
             };
             if (HAS_DQ) dqa = zero16();
@@ -796,6 +824,7 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                 dq_slice(Int2<3>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (u == 5) BSTAMP(21);
             if (HAS_DQ) {
                 // dQ rows of step u - 1 (rows >= S and the step before the first: out of the descriptor's range, dropped)
                 const int q = (u - 1) * 32 + r;
@@ -815,11 +844,13 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]}, rs_dq, off, 0, 0);
                 }
             }
+            if (u == 5) BSTAMP(22);
             // everything but this step's four pieces and (light waves) two stores: the lse words, the O rows, every older piece
             if (HAS_DQ) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             make_stats(v1, (gs + 1) & 1);
+            BSTAMP(2 + u);
         }
         int nst = 0;
         if (HAS_DQ) {
@@ -851,6 +882,7 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
             }
             nst += 2;
         }
+        BSTAMP(12);
         // dK / dV: lane = key, registers = d; the same pairing of the two lane halves into 16-byte pieces (rows >= S dropped)
         {
             const __amdgpu_buffer_rsrc_t rs_dkv = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 2 * D + 64) * 2));
@@ -881,11 +913,13 @@ __device__ __forceinline__ void bwd_wide_body(const MhaArgs& p, char* smem, cons
                     }
             }
         }
+        BSTAMP(13);
         // every piece went out before this problem's last stores: 8 NB (+ 2 on the light waves)
         if (HAS_DQ) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NB + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * NB) : "memory");
         (void)nst;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // every wave is done with this K image and with X
+        BSTAMP(14);
         pc = pn;
     }
 }
@@ -936,6 +970,6 @@ extern "C" int32_t vipant_debug_attnw_trace(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attnw_trace), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -1;
 }
 extern "C" int32_t vipant_debug_attnw_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attnw_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attnw_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           float* __restrict__ out, int64_t n, int64_t rpi, int D) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        const int64_t r = i * rpi + (idx != nullptr ? (idx[i] < 0 ? 0 : (idx[i] >= rpi ? rpi - 1 : idx[i])) : 0);      // clamped into the item
         for (int c = lane * 4; c < D; c += 256) *(f32x4*)(out + i * D + c) = *(const f32x4*)(x + r * D + c);
     }
 }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
                                                            float* __restrict__ dx, int64_t n, int64_t rpi, int D) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        const int64_t r = i * rpi + (idx != nullptr ? (idx[i] < 0 ? 0 : (idx[i] >= rpi ? rpi - 1 : idx[i])) : 0);      // clamped into the item
         for (int c = lane * 4; c < D; c += 256) {
             float* d = dx + r * D + c;
             *(f32x4*)d = *(const f32x4*)d + *(const f32x4*)(g + i * D + c);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const float* __r
                                                                 int64_t rpi, int D) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        const int64_t r = i * rpi + (idx != nullptr ? (idx[i] < 0 ? 0 : (idx[i] >= rpi ? rpi - 1 : idx[i])) : 0);      // clamped into the item
         for (int c = lane * 4; c < D; c += 256) {
             const bf16x4 v = f32x4_to_bf16x4(*(const f32x4*)(g + i * D + c));
             *(bf16x4*)(dx + r * D + c) = v;

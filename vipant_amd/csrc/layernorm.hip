@@ -242,7 +242,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
 // at M = 161 792 with fp16 rows 188-190 us for 256 workgroups; 226 / 220 / 222 / 201-205 us for 192 / 320 / 384 / 512; 8-wave
 // workgroups 200-206 us; the round-2 kernel (one row per wave, 512 workgroups) 226 us.  VIPANT_LN_BLOCKS overrides (timing only)
 int ln_blocks(int64_t M) {
-    static const int cap = getenv("VIPANT_LN_BLOCKS") ? atoi(getenv("VIPANT_LN_BLOCKS")) : 256;      // timing experiments
+    static const int env = getenv("VIPANT_LN_BLOCKS") ? atoi(getenv("VIPANT_LN_BLOCKS")) : 256;      // timing experiments
+    static const int cap = env < 1 ? 1 : env;          // (0 or a negative value would launch no workgroup)
     int64_t b = ceil_div(M, 16);
     return (int)(b > cap ? cap : b);
 }

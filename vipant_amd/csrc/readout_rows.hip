@@ -14,6 +14,14 @@
 
 namespace {
 
+// the read-out row of item i, clamped into [0, rows): an index outside the item's rows (a caller bug: the end-of-text search
+// cannot produce one) must not turn into an out-of-bounds access of qkv / dqkv / the stream
+__device__ __forceinline__ int row_index(const int64_t* idx, int64_t i, int rows) {
+    if (idx == nullptr) return 0;
+    const int64_t v = idx[i];
+    return (int)(v < 0 ? 0 : (v >= rows ? rows - 1 : v));
+}
+
 constexpr int RW = 4;                 // waves (= (item, head) pairs) per workgroup
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_fwd_kernel(const bf16_t* __r
     const int i = active ? pair / H : 0, h = active ? pair % H : 0;
     const int D = H * 64;
     const int64_t ld = 3 * (int64_t)D;
-    const int nkeys = causal ? (int)(idx != nullptr ? idx[i] : 0) + 1 : S;
+    const int nkeys = causal ? row_index(idx, i, S) + 1 : S;
     float* sc = sm + wave * S;
     const bf16_t* kbase = qkv + (int64_t)i * S * ld + D + h * 64;
     const int kl = lane >> 3, piece = (lane & 7) * 8;
@@ -80,6 +88,9 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_fwd_kernel(const bf16_t* __r
             }
         }
         mx = wave_max(mx);
+        // (the scores of a pair are written by some lanes of this wave and read by others: one wave's LDS operations execute in
+        // program order, the wave barrier only keeps the compiler from moving a read above the writes)
+        __builtin_amdgcn_wave_barrier();
         float sum = 0.f;
         for (int j = lane; j < S; j += 64) {
             const float p = j < nkeys ? __builtin_amdgcn_exp2f((sc[j] - mx) * LOG2E) : 0.f;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_bwd_kernel(const bf16_t* __r
     const int i = active ? pair / H : 0, h = active ? pair % H : 0;
     const int D = H * 64;
     const int64_t ld = 3 * (int64_t)D;
-    const int nkeys = causal ? (int)(idx != nullptr ? idx[i] : 0) + 1 : S;
+    const int nkeys = causal ? row_index(idx, i, S) + 1 : S;
     float* sc = sm + wave * S;
     const int64_t base = (int64_t)i * S * ld + D + h * 64;
     const bf16_t* kbase = qkv + base;
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(RW * 64) void mha_rows_bwd_kernel(const bf16_t* __r
             }
         }
         const float delta = wave_sum(dl);
+        __builtin_amdgcn_wave_barrier();
         // dK_j, dV_j rows (8 keys per wave store instruction, whole 128-byte rows), ds_j kept for the dq pass; dq accumulated
         // on the way: lane holds its 8 dimensions of sum_{j = kl mod 8} ds_j K_j
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
                                                           char* __restrict__ dst, int64_t n, int64_t rpi, int64_t row_bytes) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        const int64_t r = i * rpi + row_index(idx, i, (int)rpi);
         for (int64_t c = (int64_t)lane * 16; c < row_bytes; c += 64 * 16)
             *(u32x4*)(dst + i * row_bytes + c) = *(const u32x4*)(src + r * row_bytes + c);
     }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ x, c
                                                        const void* __restrict__ add, int64_t n, int64_t rpi, int D) {
     const int lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
-        const int64_t r = i * rpi + (idx != nullptr ? idx[i] : 0);
+        const int64_t r = i * rpi + row_index(idx, i, (int)rpi);
         for (int c = lane * 4; c < D; c += 256) {
             bf16x4* px = (bf16x4*)(x + r * D + c);
             const bf16x4 v = *px;

@@ -326,8 +326,13 @@ def cached_bf16(w: torch.Tensor, transpose_only: bool = False):
 # [M, D] matrix of zeros with `batch` non-zero rows (a 497 MB fill + a cast back to bf16 at cfg2), for the stack a bf16 -> fp32
 # cast that the patch embedding's LayerNorm backward immediately undoes.  When a node finds its neighbour in the autograd graph,
 # it hands the compact form over directly (an attribute on the neighbour's ctx) and returns a zero-stride placeholder of the
-# right shape; the receiver uses the hand-off only if what autograd delivers IS that placeholder (another consumer of the same
-# tensor makes autograd sum real gradients into it, and the dense path takes over, with the hand-off added in).
+# right shape; the receiver uses the hand-off only if what autograd delivers IS that placeholder -- the very allocation the sender
+# made, checked by address, not by shape (another consumer of the same tensor makes autograd sum real gradients into a new tensor,
+# and the dense path takes over, with the hand-off added in).  Guards (round 4): a tensor that retains its gradient or
+# carries hooks at forward time is never handed around (the hook would see zeros); a hand-off the receiver never consumed -- a
+# partial backward over the sender only -- is dropped by the sender's next backward instead of being added a second time; the
+# sender keeps its link to the receiver across backward calls (retain_graph).  Hooks registered on the stream AFTER the forward
+# cannot be seen from here: they observe the placeholder (zeros); VIPANT_NODE_HANDOFF=0 gives dense gradients everywhere.
 _VIEW_NODES = ("ViewBackward0", "ReshapeAliasBackward0", "UnsafeViewBackward0", "AliasBackward0", "ViewBackward1")
 
 
@@ -338,6 +343,8 @@ def _producer(t: torch.Tensor, kind: str):
     """The custom node of `kind` that produced `t` (looking through view / reshape nodes), or None."""
     if not NODE_HANDOFF:
         return None
+    if getattr(t, "retains_grad", False) or getattr(t, "_backward_hooks", None):
+        return None                                  # somebody watches this tensor's gradient: keep it dense
     node = t.grad_fn
     for _ in range(4):
         if node is None:
@@ -354,8 +361,10 @@ def _placeholder(shape, device) -> torch.Tensor:
     return torch.zeros((), dtype=F32, device=device).expand(*shape)
 
 
-def _is_placeholder(t: torch.Tensor) -> bool:
-    return t.dim() == 2 and t.stride() == (0, 0)
+def _is_placeholder(t: torch.Tensor, ph: torch.Tensor) -> bool:
+    """`t` is the placeholder `ph` a neighbour returned to autograd: the same 4-byte allocation seen through zero strides (autograd
+    may re-wrap the tensor on the way; it cannot give another tensor this address while `ph` is alive)."""
+    return ph is not None and t.dim() == 2 and t.stride() == (0, 0) and t.data_ptr() == ph.data_ptr()
 
 
 # ---------------------------------------------------------------------------------- patch embedding
@@ -400,13 +409,13 @@ class PatchEmbedFn(torch.autograd.Function):
         b, P, D, Cw, khw, mean_ch, conv_shape, pos_shape = ctx.meta
         dev = dout.device
         handed, ctx.stream_grad = ctx.stream_grad, None
-        dout_bf16 = handed is not None and _is_placeholder(dout)
+        dout_bf16 = handed is not None and _is_placeholder(dout, handed[1])
         if dout_bf16:
-            dout = handed
+            dout = handed[0]
         else:
             dout = dout.contiguous()
             if handed is not None:      # another consumer of the stream contributed a real gradient: add the stack's to it
-                dout = dout + handed.to(F32)
+                dout = dout + handed[0].to(F32)
         kcols = patches.shape[1]
         dtok = torch.empty_like(tok)
         dpatch = torch.empty((b * P, D), dtype=BF16, device=dev)
@@ -530,7 +539,10 @@ class BackboneFn(torch.autograd.Function):
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
             if prune and l == L - 1:
-                # the last block on the read-out rows (bf16 contractions whatever `fp8` says: they are `batch`-row launches)
+                # the last block on the read-out rows: bf16 contractions whatever `fp8` says.  All but one are `batch`-row launches; the
+                # exception is the K / V projection over every token (N = 2 D): it stays bf16 too, a documented departure from
+                # `running.fp8_gemm` for this one launch per tower (1 of 97 contraction launches; `running.last_block_rows=False`
+                # restores the e4m3 last block; both corners are under test_end_to_end_golden_e4m3)
                 def newr(cols, dtype=BF16):
                     return torch.empty((batch, cols), dtype=dtype, device=dev)
                 xs = new(D, SDT) if y_prev is not None else None
@@ -613,24 +625,27 @@ class BackboneFn(torch.autograd.Function):
         # backward 10 instead of 16 B per element); the forward stream stays fp32, so the loss and the features are untouched and
         # the gradients move from ~1.3 % to ~1.6 % rel-L2 of the fp32 reference (profiles/r2_stream_precision.md, model D; the
         # reference's own GPU path keeps this stream in fp16).  VIPANT_GRAD_STREAM=fp32: fp32 master + bf16 copy, both in place.
+        if ctx.wts is None:
+            raise _ffi.VipantError("BackboneFn: second backward through the same forward -- the node releases its bf16 weight copies "
+                                   "and saved activations' bookkeeping in its first backward (retain_graph re-entry is not supported)")
         handed, ctx.readout_grad = ctx.readout_grad, None
         top_rows = None
         if prune:
             # the gradient arrives for the read-out rows only, [batch, D]: dense, or handed over by the read-out node
             if handed is not None:
-                dx_in = handed[1] if _is_placeholder(dx_in) else dx_in + handed[1]
+                dx_in = handed[1] if _is_placeholder(dx_in, handed[2]) else dx_in + handed[1]
             dx, dx_b = None, None
             dxr_b = cast_bf16_flat(dx_in.contiguous())
-        elif handed is not None and _is_placeholder(dx_in) and not GRAD_STREAM_F32:
+        elif handed is not None and _is_placeholder(dx_in, handed[2]) and not GRAD_STREAM_F32:
             # the read-out's gradient as compact rows: they go straight into a zeroed bf16 stream gradient
-            ridx, rows = handed
+            ridx, rows, _ = handed
             dx = None
             dx_b = torch.zeros((M, D), dtype=BF16, device=dev)
             top_rows = torch.empty((rows.shape[0], D), dtype=BF16, device=dev)
             call("vipant_scatter_rows_bf16", rows.data_ptr(), _ptr(ridx), dx_b.data_ptr(), top_rows.data_ptr(), rows.shape[0], S, D, st)
         else:
             if handed is not None:                       # dense gradient from another consumer: add the read-out rows to it
-                ridx, rows = handed
+                ridx, rows, _ = handed
                 dx_in = dx_in.contiguous().clone()
                 call("vipant_scatter_rows", rows.data_ptr(), _ptr(ridx), dx_in.data_ptr(), rows.shape[0], S, D, st)
             if GRAD_STREAM_F32:
@@ -735,11 +750,11 @@ class BackboneFn(torch.autograd.Function):
             lg = lg_below
         ctx.wts = None
         need = ctx.needs_input_grad
-        patch, ctx.patch_node = ctx.patch_node, None
+        patch = ctx.patch_node                      # kept: a second backward over a retained graph hands over again
         if dx is None and need[0]:
             if patch is not None:        # the patch embedding's LayerNorm backward takes the bf16 stream gradient as it is
-                patch.stream_grad = dx_b
                 dx = _placeholder((M, D), dev)
+                patch.stream_grad = (dx_b, dx)      # (whatever an earlier, never-consumed hand-off left there is replaced)
             else:
                 dx = torch.empty((M, D), dtype=F32, device=dev)
                 call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
@@ -788,8 +803,10 @@ class ReadoutFn(torch.autograd.Function):
         dout = dout.contiguous()
         dfeat = torch.empty((batch, E), dtype=BF16, device=dev)
         dy = torch.empty((batch, D), dtype=BF16, device=dev)
-        stack, ctx.stack_node = ctx.stack_node, None
-        compact = stack is not None and stack.readout_grad is None and ctx.needs_input_grad[0]
+        stack = ctx.stack_node                       # kept across backward calls (retain_graph)
+        if stack is not None and stack.readout_grad is not None:
+            stack.readout_grad = None                # left by a backward in which the stack's node never ran: not this call's business
+        compact = stack is not None and ctx.needs_input_grad[0]
         drows = torch.empty((batch, D), dtype=F32, device=dev) if (idx is not None or compact) else None
         dproj = torch.empty((D, E), dtype=F32, device=dev)
         dlnw = torch.empty((D,), dtype=F32, device=dev)
@@ -801,8 +818,8 @@ class ReadoutFn(torch.autograd.Function):
              dy.data_ptr(), _ptr(drows), _ptr(dx), dproj.data_ptr(), dlnw.data_ptr(), dlnb.data_ptr(), batch, S, D, E,
              int(normalized), ws.data_ptr(), ws.numel(), _stream())
         if compact:                  # hand the rows to the stack's backward; autograd gets a zero-stride placeholder
-            stack.readout_grad = (idx, drows)
             dx = _placeholder(tuple(x.shape), dev)
+            stack.readout_grad = (idx, drows, dx)
         return dx, None, None, None, dlnw, dlnb, dproj, None
 
 
