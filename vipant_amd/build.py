@@ -92,10 +92,10 @@ def _probe_flags():
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "p.hip")
         with open(src, "w") as f:
-            f.write("__global__ void k() {}\n")
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src, "-o", os.path.join(d, "p.o")],
-                           stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
-    if r.returncode != 0:
+            f.write("#include <hip/hip_runtime.h>\n__global__ void k() {}\n")
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src, "-o",
+                            os.path.join(d, "p.o")], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    if r.returncode != 0 and "nknown command line argument" in (r.stderr or ""):
         print("[vipant_amd.build] WARNING: this hipcc does not know -mllvm -amdgpu-mfma-vgpr-form; building the attention kernels "
               "without it (slower single-pass backward)", flush=True)
         for k, v in EXTRA_CFLAGS.items():
