@@ -17,7 +17,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel", "mha_fwd_kernel<20", "mha_bwd_dq_kernel<20", "mha_bwd_dkv_kernel<20", "ln_fwd_kernel",
+KEEP = ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel", "mha_fwd_kernel<20", "mha_fwd_wide_kernel", "mha_bwd1s_kernel", "mha_bwd1_kernel", "mha_bwd_wide_kernel", "mha_bwd_dq_kernel<20", "mha_bwd_dkv_kernel<20", "ln_fwd_kernel",
         "ln_bwd_kernel", "nce_tile_kernel")
 
 
@@ -41,7 +41,7 @@ def main():
         grid[r["Dispatch_Id"]] = int(r.get("Grid_Size", 0) or 0)
     res = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
                      "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 "
-                     "--no-cpu-baseline (MI355X, round 2; tools/pmc_sq.py); per-launch averages over the largest-problem launches",
+                     "--no-cpu-baseline (MI355X; tools/pmc_sq.py); per-launch averages over the largest-problem launches",
            "kernels": []}
     for short, disp in sorted(per.items()):
         ids = list(disp)
