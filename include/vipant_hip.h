@@ -139,6 +139,25 @@ int32_t vipant_mha_rows_fwd(const uint16_t* q_rows, const uint16_t* qkv, const i
 int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const int64_t* idx, const float* probs,
                             const uint16_t* dout_rows, uint16_t* dq_rows, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H,
                             int32_t causal, void* stream);
+/* The same one-query attention with the K / V projection folded into the query side (csrc/readout_ctx.hip): with one query per
+ * (item, head) the scores are (W_k,h^T q_h) . h1_j / 8 (+ a constant the softmax drops) and the head's output is
+ * W_v,h (sum_j p_j h1_j) + b_v,h, so the kernels run against the LayerNorm output h1 bf16 [batch*S, D] itself and the key / value
+ * projection of every token (nn.MultiheadAttention's in_proj, clip/model.py:170-187 via cvap/module/val.py:519-522) is never formed.
+ * qk bf16 [batch*H, D]: row (i, h) = W_k,h^T q_(i,h);  ctx bf16 [batch*H, D]: row (i, h) = sum_j p_j h1[i, j, :];
+ * probs fp32 [batch, H, S] as above.  H = 8, 12 or 16 heads of 64 (D = 64 H); S <= 2048. */
+int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_t* idx, uint16_t* ctx, float* probs, int64_t batch,
+                            int64_t S, int64_t H, int32_t causal, void* stream);
+/* dctx bf16 [batch*H, D]: row (i, h) = W_v,h^T dout_(i,h).  dh1 bf16 [batch*S, D]: the attention's gradient for EVERY token's h1 row
+ * (zeros behind a causal limit; all rows written);  dqk bf16 [batch*H, D]: gradient of qk. */
+int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1, const int64_t* idx,
+                            const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S, int64_t H, int32_t causal,
+                            void* stream);
+/* rows bf16 [n, 64 H] -> out bf16 [n*H, 64 H]: row (i, h) = row i with every column outside head h's 64 zeroed -- the operand that
+ * makes "per-head slice times the head's weight block" one [n*H, D] x [D, D] contraction. */
+int32_t vipant_head_expand(const uint16_t* rows, uint16_t* out, int64_t n, int64_t H, void* stream);
+/* its inverse on a product: rows[i, 64 h + c] = full[(i, h), 64 h + c] (+ bias[64 h + c]); full bf16 or fp32 [n*H, 64 H]. */
+int32_t vipant_head_extract(const void* full, int32_t full_is_f32, const float* bias, uint16_t* rows, int64_t n, int64_t H,
+                            void* stream);
 /* dst row i <- src row (i * rows_per_item + idx[i]) (idx == NULL: + 0); rows of row_bytes bytes, a multiple of 16. */
 int32_t vipant_gather_rows_bytes(const void* src, const int64_t* idx, void* dst, int64_t n, int64_t rows_per_item, int64_t row_bytes,
                            void* stream);

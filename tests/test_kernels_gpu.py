@@ -414,6 +414,64 @@ def test_mha_rows(ops, batch, S, H, causal, with_idx):
     assert float(qr.grad[:, :D][mask].abs().max()) == 0.0        # the premise: no query gradient off the read-out rows
 
 
+@pytest.mark.parametrize("batch,S,H,causal,with_idx", [(3, 316, 12, False, False), (4, 77, 8, True, True), (2, 50, 12, False, True),
+                                                       (3, 257, 16, False, False), (2, 5, 8, True, True), (2, 645, 12, False, False)])
+def test_rows_ctx(ops, batch, S, H, causal, with_idx):
+    """The one-query attention of the last block with the K / V projection folded into the query side (csrc/readout_ctx.hip) against
+    its definition in fp64 autograd: contexts, softmax rows, dh1 of every token, dqk."""
+    D = H * 64
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    idx = torch.randint(0, S, (batch,), generator=g).to(DEV) if with_idx else None
+    if with_idx and causal:
+        idx[0] = S - 1; idx[1] = 0          # the whole sequence / a single key
+    qk = rnd(batch * H, D, seed=1, dtype=torch.bfloat16, scale=0.35)
+    h1 = rnd(batch * S, D, seed=2, dtype=torch.bfloat16)
+    ctx = torch.full((batch * H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    probs = torch.full((batch, H, S), 7.0, dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ip = idx.data_ptr() if idx is not None else None
+    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S, H, int(causal), st)
+    qd = qk.double().view(batch, H, D).requires_grad_()
+    hd = h1.double().view(batch, S, D).requires_grad_()
+    sc = torch.einsum("bhd,bsd->bhs", qd, hd) / 8.0
+    if causal:
+        lim = (idx if idx is not None else torch.zeros(batch, dtype=torch.long, device=DEV)).view(batch, 1, 1)
+        sc = sc.masked_fill(torch.arange(S, device=DEV).view(1, 1, S) > lim, float("-inf"))
+    pd = torch.softmax(sc, -1)
+    ref = torch.einsum("bhs,bsd->bhd", pd, hd)
+    assert_close(probs, pd, 2e-3, 1e-5, "rows_ctx softmax rows")
+    assert_close(ctx.view(batch, H, D), ref, 1e-2, 1e-2, "rows_ctx contexts")
+    dctx = rnd(batch * H, D, seed=3, dtype=torch.bfloat16)
+    ref.backward(dctx.double().view(batch, H, D))
+    dh1 = torch.full((batch * S, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    dqk = torch.full((batch * H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), ip, probs.data_ptr(), dh1.data_ptr(),
+             dqk.data_ptr(), batch, S, H, int(causal), st)
+    assert_close(dh1.view(batch, S, D), hd.grad, 2e-2, 2e-2 * hd.grad.abs().max().item(), "rows_ctx dh1")
+    assert_close(dqk.view(batch, H, D), qd.grad, 2e-2, 2e-2 * qd.grad.abs().max().item(), "rows_ctx dqk")
+    if causal:          # rows behind the limit get exact zeros, not the fill
+        lim = idx if idx is not None else torch.zeros(batch, dtype=torch.long, device=DEV)
+        behind = torch.arange(S, device=DEV).view(1, S) > lim.view(batch, 1)
+        assert float(dh1.view(batch, S, D)[behind].abs().max() if behind.any() else 0.0) == 0.0
+
+
+def test_head_expand_extract(ops):
+    for n, H in ((5, 12), (3, 8), (2, 16)):
+        D = 64 * H
+        rows = rnd(n, D, seed=1, dtype=torch.bfloat16)
+        x = ops.head_expand(rows, H).view(n, H, H, 64)
+        for h in range(H):
+            assert torch.equal(x[:, h, h], rows.view(n, H, 64)[:, h])
+            x[:, h, h] = 0
+        assert float(x.abs().max()) == 0.0
+        bias = rnd(D, seed=2)
+        for dt in (torch.bfloat16, torch.float32):
+            full = rnd(n * H, D, seed=3).to(dt)
+            diag = torch.stack([full.view(n, H, H, 64)[:, h, h] for h in range(H)], 1).reshape(n, D).float()
+            assert torch.equal(ops.head_extract(full, H), diag.to(torch.bfloat16))
+            assert torch.equal(ops.head_extract(full, H, bias), (diag + bias).to(torch.bfloat16))
+
+
 def test_gather_and_add_rows(ops):
     batch, S, D = 5, 9, 768
     idx = torch.tensor([0, 8, 3, 3, 7], device=DEV)

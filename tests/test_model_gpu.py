@@ -363,45 +363,90 @@ def test_node_handoff_with_other_consumers(M, monkeypatch):
         assert rel_l2(g1[k], g0[k]) < 2e-3, (k, rel_l2(g1[k], g0[k]))     # bf16 rounding of (a + b) vs a, b separately
 
 
-def _tower_step(M, kind, last_block_rows, layers):
+def _tower_inputs(kind, layers):
+    if kind == "audio":
+        b, w = 6, None
+        x = gen.det_randn("rows/aud", (b, 1, 256, 64))
+    else:
+        b = 5 if kind == "text" else 2          # "text2": two clips, the smallest batch with a negative
+        w = gen.det_weights("text/l2", gen.text_head_shapes(512, layers, 512))
+        x = gen.det_tokens("rows/tok", b)
+    other = gen.det_randn(f"rows/other/{kind}", (b, 512))
+    return b, w, x, other
+
+
+def _tower_step(M, kind, last_block_rows, layers, ctx_form=True):
     """One loss + backward through a trainable tower; returns (features, loss, gradients)."""
     from vipant_amd import ops
+    b, w, x, other = _tower_inputs(kind, layers)
     if kind == "audio":
-        b = 6
         head = M.build_audio_head(audio_cfg(256, 64, layers))
         S = head.misc.positional_embedding.shape[0]
         head.load_state_dict(gen.det_weights("e2e/L2", gen.vit_head_shapes(768, layers, 512, S)), strict=True)
-        x = gen.det_randn("rows/aud", (b, 1, 256, 64)).to(DEV)
     else:
-        b = 5 if kind == "text" else 2          # "text2": two clips, the smallest batch with a negative
         head = M.build_text_head(text_cfg(layers))
-        head.load_state_dict(gen.det_weights("text/l2", gen.text_head_shapes(512, layers, 512)), strict=True)
-        x = gen.det_tokens("rows/tok", b).to(DEV)
+        head.load_state_dict(w, strict=True)
+    x = x.to(DEV)
     lhead = M.build_loss_head(NS(name="CELossHead", layers=[], scaling=True, scale_max=None))
     head, lhead = head.to(DEV).train(), lhead.to(DEV).train()
     head.encoder.last_block_rows = last_block_rows
-    other = ops.l2_normalize(gen.det_randn(f"rows/other/{kind}", (b, 512)).to(DEV))
-    feat = head(x, normalized=True)
-    loss = lhead(other, feat, None, normalized=True)
-    loss.backward()
+    other = ops.l2_normalize(other.to(DEV))
+    keep, ops.LAST_BLOCK_CTX = ops.LAST_BLOCK_CTX, ctx_form
+    try:
+        feat = head(x, normalized=True)
+        loss = lhead(other, feat, None, normalized=True)
+        loss.backward()
+    finally:
+        ops.LAST_BLOCK_CTX = keep
     return feat.detach(), float(loss), {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}
+
+
+def _tower_step_oracle(kind, layers):
+    """The same step through the CPU restatement of the reference (fp32): the value both HIP realisations approximate."""
+    from oracle import ref_cpu as R
+    b, w, x, other = _tower_inputs(kind, layers)
+    if kind == "audio":
+        stride, S, pr = R.vit_position_resolution([256, 64], 32, [16, 24])
+        w = gen.det_weights("e2e/L2", gen.vit_head_shapes(768, layers, 512, S))
+    w = {k: v.clone().requires_grad_() for k, v in w.items()}
+    if kind == "audio":
+        feat = R.vit_head_forward(x, w, width=768, layers=layers, stride=stride, position_resolution=pr)
+    else:
+        feat = R.text_head_forward(x, w, layers=layers)
+    loss = R.ce_loss_head(R.l2_normalize(other), feat, torch.tensor(math.log(1 / 0.07)))
+    loss.backward()
+    return feat.detach(), float(loss), {k: v.grad for k, v in w.items() if v.grad is not None}
 
 
 @pytest.mark.parametrize("kind,layers", [("audio", 2), ("audio", 1), ("text", 2), ("text2", 1)])
 def test_last_block_on_readout_rows_matches_full_block(M, kind, layers):
     """`running.last_block_rows` (ops.BackboneFn `rows`): the last block evaluated on the read-out rows only -- class token of the
-    audio ViT, end-of-text token of the causal text tower -- against the full block: same features, loss and gradient of EVERY
-    parameter (the last block's included), up to the rounding of a different summation order."""
-    f0, l0, g0 = _tower_step(M, kind, False, layers)
-    f1, l1, g1 = _tower_step(M, kind, True, layers)
-    assert rel_err(f1, f0) < 8e-3, rel_err(f1, f0)        # two bf16 realisations of the same features: observed 2.1e-3 ... 5.8e-3
-    assert abs(l1 - l0) < 2e-3, (l0, l1)
-    assert sorted(g0) == sorted(g1)
-    worst = max((rel_l2(g1[k], g0[k]), k) for k in g0)
-    observe(f"last_block_rows_{kind}_L{layers}:{worst[1]}", feat_rel_err=rel_err(f1, f0), loss_abs_diff=abs(l1 - l0),
-            worst_grad_rel_l2=worst[0])
-    for k in g0:
-        assert rel_l2(g1[k], g0[k]) < 2e-2, (k, rel_l2(g1[k], g0[k]))
+    audio ViT, end-of-text token of the causal text tower -- in both of its forms (key / value projection folded into the query
+    side: csrc/readout_ctx.hip, the default; K and V of every token: csrc/readout_rows.hip) against the full block AND against the
+    CPU restatement of the reference: the three HIP realisations are bf16 roundings of the same function in different orders, so
+    they must sit equally close to the fp32 value -- features, loss, the gradient of EVERY parameter (the last block's included)."""
+    fo, lo, go = _tower_step_oracle(kind, layers)
+    runs = {"full": _tower_step(M, kind, False, layers), "rows_kv": _tower_step(M, kind, True, layers, ctx_form=False),
+            "rows_ctx": _tower_step(M, kind, True, layers, ctx_form=True)}
+    f0, l0, g0 = runs["full"]
+    err = {}
+    for name, (f1, l1, g1) in runs.items():
+        assert set(g1) <= set(go)
+        worst = max((rel_l2(g1[k], go[k]), k) for k in g1)
+        err[name] = (rel_err(f1, fo), abs(l1 - lo), worst[0])
+        observe(f"last_block_{name}_{kind}_L{layers}:{worst[1]}", feat_rel_err_oracle=rel_err(f1, fo), loss_abs_err_oracle=abs(l1 - lo),
+                worst_grad_rel_l2_oracle=worst[0], feat_rel_err_full=rel_err(f1, f0), loss_abs_diff_full=abs(l1 - l0))
+    for name, (f1, l1, g1) in runs.items():
+        # against the oracle: the budgets of the golden-vector tests of these towers (features 2e-2: test_text_head_golden; loss:
+        # E2E_LOSS_BUDGET of a batch this small, 8e-3 for the two-clip case), and no further from it than the full block is
+        assert err[name][0] < 2e-2 and err[name][0] < 1.5 * err["full"][0] + 2e-3, (name, err)
+        assert err[name][1] < (8e-3 if kind == "text2" else 4e-3), (name, err)
+        assert err[name][2] < 3e-2 and err[name][2] < 1.5 * err["full"][2] + 2e-3, (name, err)
+        # against the full block: two bf16 realisations of the same function (observed: profiles/r4_parity_observed.jsonl)
+        assert rel_err(f1, f0) < 8e-3 and abs(l1 - l0) < (8e-3 if kind == "text2" else 4e-3), (name, rel_err(f1, f0), l0, l1)
+        # (two clips: the 2 x 2 logits at scale 1 / 0.07 turn the features' rounding into the largest gradient differences seen here)
+        for k in g0:
+            assert rel_l2(g1[k], g0[k]) < (3e-2 if kind == "text2" else 2e-2), (name, k, rel_l2(g1[k], g0[k]))
 
 
 @pytest.mark.parametrize("rows", [True, False], ids=["rows", "fullblock"])

@@ -41,3 +41,32 @@ for name, fn, nbytes in (("fwd", fwd, 2 * b * S * D * 2), ("bwd", bwd, 4 * b * S
     ts.sort()
     med = ts[len(ts) // 2]
     print(f"mha_rows_{name}: median {med * 1e3:.1f} us  best {ts[0] * 1e3:.1f} us  {nbytes / med / 1e6:.0f} GB/s of K|V (+dK|dV) bytes")
+
+# the same attention with the K / V projection folded into the query side (csrc/readout_ctx.hip): one pass over h1
+h1 = torch.randn(b * S, D, device=dev).to(torch.bfloat16)
+qk = (torch.randn(b * H, D, device=dev) * 0.35).to(torch.bfloat16)
+hctx = torch.empty(b * H, D, dtype=torch.bfloat16, device=dev)
+dctx = torch.randn(b * H, D, device=dev).to(torch.bfloat16)
+dh1 = torch.empty_like(h1)
+dqk = torch.empty_like(qk)
+
+
+def cfwd():
+    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, hctx.data_ptr(), probs.data_ptr(), b, S, H, 0, st)
+
+
+def cbwd():
+    ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
+             dqk.data_ptr(), b, S, H, 0, st)
+
+
+for name, fn, nbytes in (("fwd", cfwd, b * S * D * 2), ("bwd", cbwd, 2 * b * S * D * 2)):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    med = ts[len(ts) // 2]
+    print(f"rows_ctx_{name}: median {med * 1e3:.1f} us  best {ts[0] * 1e3:.1f} us  {nbytes / med / 1e6:.0f} GB/s of h1 (+dh1) bytes")

@@ -450,6 +450,28 @@ class _LayerGrads:
 
 # precision of the residual-stream GRADIENT: `running.grad_stream` (bf16 | fp32; monitor.py sets it), default from the environment
 GRAD_STREAM_F32 = os.environ.get("VIPANT_GRAD_STREAM", "bf16") == "fp32"
+# the last block's one-query attention with the key / value projection folded into the query side (csrc/readout_ctx.hip);
+# 0: project every token to K and V and attend over those (csrc/readout_rows.hip, the round-3 form)
+LAST_BLOCK_CTX = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0"
+
+
+def head_expand(rows: torch.Tensor, H: int) -> torch.Tensor:
+    """rows bf16 [n, 64 H] -> [n * H, 64 H]: row (i, h) keeps head h's 64 columns of row i, zeros elsewhere."""
+    _need(rows, BF16, "head_expand.rows")
+    n, D = rows.shape
+    assert D == 64 * H and rows.is_contiguous()
+    out = torch.empty((n * H, D), dtype=BF16, device=rows.device)
+    call("vipant_head_expand", rows.data_ptr(), out.data_ptr(), n, H, _stream())
+    return out
+
+
+def head_extract(full: torch.Tensor, H: int, bias=None) -> torch.Tensor:
+    """full bf16 | fp32 [n * H, 64 H] -> bf16 [n, 64 H]: head h's 64 columns of row (i, h) (+ bias)."""
+    nH, D = full.shape
+    assert D == 64 * H and nH % H == 0 and full.is_contiguous() and full.dtype in (BF16, F32)
+    out = torch.empty((nH // H, D), dtype=BF16, device=full.device)
+    call("vipant_head_extract", full.data_ptr(), int(full.dtype == F32), _ptr(bias), out.data_ptr(), nH // H, H, _stream())
+    return out
 
 
 class BackboneFn(torch.autograd.Function):
@@ -508,6 +530,7 @@ class BackboneFn(torch.autograd.Function):
         if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
+        ctx_alg = prune and LAST_BLOCK_CTX and H in (8, 12, 16) and S <= 2048
         # e4m3 operands in the NT contractions (configs[4]): a property of the tower, whether or not this call records a backward --
         # the no-grad feature pass of `running.micro_batch` and evaluation must see the forward the training pass differentiates
         fp8 = bool(fp8)
@@ -528,7 +551,7 @@ class BackboneFn(torch.autograd.Function):
                 wts.append((wqkv_t, wo_t, wfc_t, wpr_t, wfc_b if recompute_mlp else None) +
                            ((wq_all[4 * l:4 * l + 4], wtq_all[4 * l:4 * l + 4]) if fp8 else (None, None)))
                 if prune and l == L - 1:         # the last block keeps its per-token activations for the read-out rows only
-                    h1, qkv = new(D), new(3 * D)
+                    h1, qkv = new(D), (None if ctx_alg else new(3 * D))
                     mean1, rstd1 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(2))
                 else:
                     h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
@@ -550,12 +573,28 @@ class BackboneFn(torch.autograd.Function):
                      mean1.data_ptr(), rstd1.data_ptr(), M, D, _ptr(y_prev), _ptr(xs), None, None, sflags(x), st)
                 if xs is not None:
                     x = xs
-                gemm_nt(h1, wqkv_b[D:], qkv[:, D:], bias=bqkv[D:], epi=EPI_BF16)         # K, V of every token
                 h1_r = gather_rows(h1, ridx, batch, S)
                 q_r = gemm_nt(h1_r, wqkv_b[:D], newr(D), bias=bqkv[:D], epi=EPI_BF16)     # Q of the read-out rows
-                o_r, probs = newr(D), torch.empty((batch, H, S), dtype=F32, device=dev)
-                call("vipant_mha_rows_fwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), o_r.data_ptr(), probs.data_ptr(), batch, S, H,
-                     int(causal), st)
+                probs = torch.empty((batch, H, S), dtype=F32, device=dev)
+                if ctx_alg:
+                    # one query per (item, head): the key projection moves to the query (qk_h = W_k,h^T q_h, the key bias drops out
+                    # of the softmax), the value projection behind the weighted sum (o_h = W_v,h sum_j p_j h1_j + b_v,h): three
+                    # [batch * H, D] x [D, D] contractions and one pass over h1 instead of K, V of every token
+                    wk_t = (wqkv_t if train else cached_bf16(wqkv, transpose_only=True))[:, D:2 * D]
+                    qkv = torch.empty((2, batch * H, D), dtype=BF16, device=dev)            # [0]: qk, [1]: the heads' contexts
+                    qx = head_expand(q_r, H)
+                    gemm_nt(qx, wk_t, qkv[0], epi=EPI_BF16)
+                    call("vipant_rows_ctx_fwd", qkv[0].data_ptr(), h1.data_ptr(), _ptr(ridx), qkv[1].data_ptr(), probs.data_ptr(),
+                         batch, S, H, int(causal), st)
+                    o_r = head_extract(gemm_nt(qkv[1], wqkv_b[2 * D:], qx, bias=bqkv[2 * D:], epi=EPI_BF16), H)
+                    del qx
+                else:
+                    if qkv is None:
+                        qkv = new(3 * D)
+                    gemm_nt(h1, wqkv_b[D:], qkv[:, D:], bias=bqkv[D:], epi=EPI_BF16)         # K, V of every token
+                    o_r = newr(D)
+                    call("vipant_mha_rows_fwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), o_r.data_ptr(), probs.data_ptr(), batch, S,
+                         H, int(causal), st)
                 y1_r = gemm_nt(o_r, wo_b, newr(D), bias=bo, epi=EPI_BF16)
                 x_r = gather_rows(x, ridx, batch, S)
                 # the read-out rows' stream stays fp32 from here, and c_proj adds it in its epilogue: the rows the features are
@@ -604,6 +643,8 @@ class BackboneFn(torch.autograd.Function):
             ctx.wts = wts
             ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8, prune)
             ctx.rows = ridx
+            ctx.last_ctx = ctx_alg
+            ctx.wqkv_b_last = wqkv_b if ctx_alg else None     # bf16 in_proj weight of the last block (its K rows: dq = W_k dqk)
             ctx.grad_sync = grad_sync
             ctx._vipant_kind = "stack"
             ctx.readout_grad = None                      # (idx | None, compact fp32 rows), handed over by ReadoutFn.backward
@@ -689,16 +730,33 @@ class BackboneFn(torch.autograd.Function):
                      _ffi.STREAM_IN_F16 if x1_r.dtype == F16 else 0, st)
                 call("vipant_gemm_bias_residual_bwd_e4m3", dxr_b.data_ptr(), wo_t.data_ptr(), o_r.data_ptr(), do_r.data_ptr(),
                      d_wo.data_ptr(), batch, D, D, ws.data_ptr(), ws.numel(), None, st)
-                dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
-                call("vipant_mha_rows_bwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), probs.data_ptr(), do_r.data_ptr(),
-                     dq_r.data_ptr(), dqkv.data_ptr(), batch, S, H, int(causal), st)
-                # dh = dK|dV . W_kv on every token, + dq . W_q on the read-out rows
-                gemm_nt(dqkv[:, D:], wqkv_t[:, D:], dh, epi=EPI_BF16)
+                if ctx.last_ctx:
+                    wqkv_b_last = ctx.wqkv_b_last
+                    # qkv = [qk | contexts] of the forward.  dctx_h = W_v,h^T do_h; the kernel gives dh of every token and dqk;
+                    # dq_h = W_k,h dqk_h; d W_v = do (x) ctx, d W_k = q (x) dqk per head (block-sparse operands), d b_k = 0
+                    qk, hctx = qkv[0], qkv[1]
+                    dox = head_expand(do_r, H)
+                    dctx = gemm_nt(dox, wqkv_t[:, 2 * D:], torch.empty((batch * H, D), dtype=BF16, device=dev), epi=EPI_BF16)
+                    gemm_tn(dox, hctx, d_wqkv[2 * D:], a_colsum=d_bqkv[2 * D:], ws_name="block_bwd")
+                    dqk = torch.empty((batch * H, D), dtype=BF16, device=dev)
+                    call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), _ptr(ridx),
+                         probs.data_ptr(), dh.data_ptr(), dqk.data_ptr(), batch, S, H, int(causal), st)
+                    dq_r = head_extract(gemm_nt(dqk, wqkv_b_last[D:2 * D], dox, epi=EPI_BF16), H)
+                    gemm_tn(head_expand(q_r, H), dqk, d_wqkv[D:2 * D], ws_name="block_bwd")
+                    d_bqkv[D:2 * D].zero_()
+                    del dox, dctx, dqk
+                else:
+                    dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
+                    call("vipant_mha_rows_bwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), probs.data_ptr(), do_r.data_ptr(),
+                         dq_r.data_ptr(), dqkv.data_ptr(), batch, S, H, int(causal), st)
+                    # dh = dK|dV . W_kv on every token
+                    gemm_nt(dqkv[:, D:], wqkv_t[:, D:], dh, epi=EPI_BF16)
+                    gemm_tn(dqkv[:, D:], h1, d_wqkv[D:], a_colsum=d_bqkv[D:], ws_name="block_bwd")
+                    del dqkv
+                # + dq . W_q on the read-out rows
                 dhq = gemm_nt(dq_r, wqkv_t[:, :D], torch.empty((batch, D), dtype=F32, device=dev), epi=EPI_F32)
                 call("vipant_add_rows_bf16", dh.data_ptr(), _ptr(ridx), dhq.data_ptr(), 1, batch, S, D, st)
-                gemm_tn(dqkv[:, D:], h1, d_wqkv[D:], a_colsum=d_bqkv[D:], ws_name="block_bwd")
                 gemm_tn(dq_r, h1_r, d_wqkv[:D], a_colsum=d_bqkv[:D], ws_name="block_bwd")
-                del dqkv
                 # ln_1 backward on every token; the residual gradient of this block exists on the read-out rows only
                 dx_b = torch.empty((M, D), dtype=BF16, device=dev)
                 call("vipant_layernorm_bwd_e4m3", dh.data_ptr(), _ffi.LN_X_F16 if x.dtype == F16 else 0, x.data_ptr(), D,
@@ -748,7 +806,7 @@ class BackboneFn(torch.autograd.Function):
             if ctx.grad_sync is not None:
                 ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
             lg = lg_below
-        ctx.wts = None
+        ctx.wts = ctx.wqkv_b_last = None
         need = ctx.needs_input_grad
         patch = ctx.patch_node                      # kept: a second backward over a retained graph hands over again
         if dx is None and need[0]:
