@@ -40,6 +40,12 @@ extern "C" {
 #define VIPANT_EPI_SCALE_F32 5     /* C_f32  = alpha * acc */
 #define VIPANT_EPI_QUICKGELU_D8 6  /* as QUICKGELU, but aux receives uint8 codes of QuickGELU'(U) instead of U (1 B / element) */
 #define VIPANT_EPI_DQUICKGELU_D8 7 /* C_bf16 = acc * decode(aux uint8): backward of c_fc act from the 8-bit derivative code */
+/* OR-ed into `epilogue`: the rows of this launch are ONE ROW PER ITEM of a batch (the last block on its read-out rows, the read-out
+ * projection).  Such launches take 64 x 64 tiles with K split over the waves of a workgroup instead of 256 x 256 tiles (21-91 us ->
+ * 9-30 us at 512 rows).  A property of the call site, not of M: a row's result must not depend on how many rows travel with it
+ * (`running.micro_batch` reproduces the full-batch loss to 1e-6), so the kernel choice may not either.  Epilogues: BF16, F32,
+ * RESIDUAL_F32, QUICKGELU_D8, DQUICKGELU_D8. */
+#define VIPANT_EPI_FEW_ROWS 0x100
 
 const char* vipant_last_error(void);
 int32_t vipant_version(void);
@@ -91,6 +97,7 @@ int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, co
  * statistics and the norm taken on the unrounded sum.  IN: the `x` argument is fp16; OUT: the `x_out` / `sum_out` argument is. */
 #define VIPANT_STREAM_IN_F16 1
 #define VIPANT_STREAM_OUT_F16 2
+#define VIPANT_STREAM_FEW_ROWS 0x100 /* (vipant_ln_mlp_quickgelu_bwd_e4m3) its contractions are VIPANT_EPI_FEW_ROWS launches */
 /* out fp32 [M, D] = x (fp32, or fp16 with VIPANT_STREAM_IN_F16) + add bf16 (the last block's residual add, no norm behind it). */
 int32_t vipant_residual_add(const void* x, const uint16_t* add, float* out, int64_t n, int32_t stream_flags, void* stream);
 /* dx[M,D] = dres (optional residual-stream gradient) + LN'(dy); outputs dx_f32 (optional) and dx_bf16 (optional).

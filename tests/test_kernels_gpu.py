@@ -178,6 +178,57 @@ def test_gemm_nt_quickgelu_derivative_code(ops, M, N, K):
         ops.gemm_nt(a[:, :64], b[:, :64], g, bias=bias, aux=code, epi=ops.EPI_QUICKGELU_D8)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (512, 3072, 768), (512, 768, 3072), (33, 768, 3072), (1000, 264, 128), (1, 64, 64),
+                                   (4096, 520, 448)])
+def test_gemm_nt_few_rows(ops, M, N, K):
+    """VIPANT_EPI_FEW_ROWS (the last block on its read-out rows, the read-out projection): 64 x 64 tiles, K split over the four
+    waves of a workgroup.  Every epilogue the flag accepts, against fp32 torch AND against the 256 x 256 kernels on the same
+    operands (same products, another summation order: bf16 outputs within one rounding step); a row's result does not depend on
+    the rows that travel with it (what `running.micro_batch` relies on)."""
+    a = rnd(M, K, seed=51, dtype=torch.bfloat16); b = rnd(N, K, seed=52, dtype=torch.bfloat16, scale=2.0 * K ** -0.5)
+    bias = rnd(N, seed=53); res = rnd(M, N, seed=54)
+    acc = a.float() @ b.float().t()
+    pre = acc + bias
+
+    def run(few):
+        o = {}
+        o["bf16"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV), bias=bias, epi=ops.EPI_BF16, few_rows=few)
+        o["f32"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, device=DEV), bias=bias, epi=ops.EPI_F32, few_rows=few)
+        o["f32_nobias"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, device=DEV), epi=ops.EPI_F32, few_rows=few)
+        o["res"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, device=DEV), bias=bias, aux=res, epi=ops.EPI_RESIDUAL_F32, few_rows=few)
+        r2 = res.clone()
+        o["res_inplace"] = ops.gemm_nt(a, b, r2, bias=bias, aux=r2, epi=ops.EPI_RESIDUAL_F32, few_rows=few)
+        if N % 8 == 0 and K >= 128:
+            code = torch.full((M, N), 7, dtype=torch.uint8, device=DEV)
+            o["g"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV), bias=bias, aux=code,
+                                 epi=ops.EPI_QUICKGELU_D8, few_rows=few)
+            o["code"] = code
+            o["dg"] = ops.gemm_nt(a, b, torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV), aux=code, epi=ops.EPI_DQUICKGELU_D8,
+                                  few_rows=few)
+        return o
+
+    few, big = run(True), run(False)
+    if M > 40:          # the same rows inside a smaller launch: bit for bit
+        sub = ops.gemm_nt(a[7:40], b, torch.empty((33, N), dtype=torch.bfloat16, device=DEV), bias=bias, epi=ops.EPI_BF16, few_rows=True)
+        assert torch.equal(sub, few["bf16"][7:40])
+    with pytest.raises(Exception):
+        ops.gemm_nt(a, b, torch.empty((M, N), device=DEV), epi=ops.EPI_SCALE_F32, alpha=0.5, few_rows=True)
+    assert_close(few["bf16"], pre, 1e-2, 2e-2, "bf16")
+    assert_close(few["f32"], pre, 1e-4, 3e-3, "f32")
+    assert_close(few["f32_nobias"], acc, 1e-4, 3e-3, "f32, no bias")
+    assert_close(few["res"], pre + res, 1e-4, 3e-3, "residual")
+    assert torch.equal(few["res"], few["res_inplace"])
+    for k in ("f32", "f32_nobias", "res"):
+        assert_close(few[k], big[k], 1e-5, 1e-5 * float(pre.abs().max()) + 1e-6, f"{k} vs the 256 x 256 kernel")
+    assert_close(few["bf16"], big["bf16"], 2 ** -7, 1e-3, "bf16 vs the 256 x 256 kernel")
+    if "g" in few:
+        assert_close(few["g"], pre * torch.sigmoid(1.702 * pre), 1e-2, 2e-2, "quickgelu.g")
+        dec = few["code"].float() / 212.5 - 0.1
+        assert float((dec - qgelu_prime(pre)).abs().max()) < 2.4e-3 + 6e-3
+        assert float((few["code"].int() - big["code"].int()).abs().max()) <= 2      # one code step + a flipped bf16 rounding of u
+        assert_close(few["dg"], acc * dec, 1e-2, 2e-2, "dquickgelu from the code")
+
+
 @pytest.mark.parametrize("M,N,K", [(4100, 2304, 768), (5000, 200, 64), (4096, 3072, 128), (6001, 776, 1024),
                                    (20000, 1000, 128), (66000, 256, 64)])   # >= 256 tiles with a short last round: half-tile tail kernel
 def test_gemm_nt_short_k_large_m(ops, M, N, K):

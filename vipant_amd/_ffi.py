@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIPANT_HIP_LIB") or os.path.join(_HERE, "lib", "libvipant_hip.so")   # override: A/B timing of builds
 
 EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32, EPI_QUICKGELU_D8, EPI_DQUICKGELU_D8 = range(8)
+EPI_FEW_ROWS = 0x100          # VIPANT_EPI_FEW_ROWS: one row per item of a batch (read-out rows): the 64 x 64 split-K kernel
+STREAM_FEW_ROWS = 0x100
 STREAM_IN_F16, STREAM_OUT_F16 = 1, 2          # VIPANT_STREAM_*: precision of the residual stream inside the transformer stack
 LN_DY_F32, LN_DRES_BF16, LN_X_F16 = 1, 2, 4
 

@@ -194,13 +194,15 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
                    "ln_mlp_quickgelu_bwd: workspace too small");
     // du = (dy . W_proj) * QuickGELU'(u), the derivative read from its 8-bit code;  dW_proj = dy^T g   (d b_proj is the column
     // sum the caller already has)
+    // (VIPANT_STREAM_FEW_ROWS: the operator runs on a batch's read-out rows -- bf16 only: the e4m3 contractions have one kernel)
+    const int32_t few = (plan == nullptr && (stream_flags & VIPANT_STREAM_FEW_ROWS)) ? VIPANT_EPI_FEW_ROWS : 0;
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
            plan ? plan->dy_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
-           VIPANT_EPI_DQUICKGELU_D8, stream));
+           VIPANT_EPI_DQUICKGELU_D8 | few, stream));
     TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
     TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D,
-           4 * D, VIPANT_EPI_BF16, stream));
+           4 * D, VIPANT_EPI_BF16 | few, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
     return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,
@@ -271,7 +273,7 @@ extern "C" int32_t vipant_cls_ln_proj_l2norm_fwd(const float* x, const int64_t* 
         src = rows; ld = D;
     }
     TRY(vipant_layernorm_fwd(src, ld, gamma, beta, y, nullptr, mean, rstd, batch, D, nullptr, nullptr, stream));
-    TRY(vipant_gemm_nt(y, D, proj_t, D, feat, E, nullptr, nullptr, 1.0f, batch, E, D, VIPANT_EPI_F32, stream));
+    TRY(vipant_gemm_nt(y, D, proj_t, D, feat, E, nullptr, nullptr, 1.0f, batch, E, D, VIPANT_EPI_F32 | VIPANT_EPI_FEW_ROWS, stream));
     if (normalized) return vipant_l2norm_fwd(feat, out, norm, batch, E, stream);
     return VIPANT_OK;
 }
@@ -300,7 +302,8 @@ extern "C" int32_t vipant_cls_ln_proj_l2norm_bwd(const float* dout, const float*
                    "cls_ln_proj_l2norm_bwd: workspace too small");
     if (normalized) TRY(vipant_l2norm_bwd(dout, out, norm, nullptr, dfeat, batch, E, stream));
     else TRY(vipant_cast_bf16(dout, dfeat, nullptr, 1, batch * E, stream));
-    TRY(vipant_gemm_nt(dfeat, E, proj, E, dy, D, nullptr, nullptr, 1.0f, batch, D, E, VIPANT_EPI_BF16, stream));   // dy = dfeat . proj^T
+    TRY(vipant_gemm_nt(dfeat, E, proj, E, dy, D, nullptr, nullptr, 1.0f, batch, D, E, VIPANT_EPI_BF16 | VIPANT_EPI_FEW_ROWS,
+                       stream));   // dy = dfeat . proj^T
     TRY(vipant_gemm_tn(y, D, dfeat, E, dproj, E, batch, D, E, 0, nullptr, workspace, workspace_bytes, stream));
     if (idx == nullptr) {
         // cls rows: in place in the token-major dx (row stride S * D), or -- `drows` given -- as compact rows [batch, D]: the caller

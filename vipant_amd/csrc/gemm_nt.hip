@@ -898,6 +898,120 @@ int32_t launch(const GemmNT& p, hipStream_t stream) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// Few rows (VIPANT_EPI_FEW_ROWS): the last block on its read-out rows (`batch` rows per launch) and the read-out.
+// A 256 x 256 tile leaves such a launch on 6-24 CUs for 12-48 serial K-steps (21-91 us measured at M = 512).  Here: 64 x 64 tiles
+// (96-384 workgroups), the four waves of a workgroup split K between them -- fragments straight from global memory (both
+// operands are K-contiguous, 16 bytes per lane and MFMA operand, no LDS stage) with a whole batch of K-steps in flight -- and add
+// their partial tiles through LDS; wave w then owns rows 16 w .. 16 w + 15 of the tile for the epilogue (4 consecutive columns of
+// one row per lane, as everywhere in this file).
+constexpr int SK_KB = 6;          // K-steps (of 32) a wave has in flight
+template <int EPI, int NW>       // NW waves share K.  Four: eight were tried for K = 3072 and are slower (34 against 30 us at M = 512)
+__global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* part = (f32x4*)smem;                           // [NW waves][16 tiles][64 lanes]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int ntn = (p.N + 63) / 64;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const bf16_t *ap[4], *bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * i + r, n = n0 + 16 * i + r;
+        ap[i] = p.A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + 8 * g;
+        bp[i] = p.B + (int64_t)(n < p.N ? n : p.N - 1) * p.ldb + 8 * g;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = p.K / 32;
+    for (int s0 = wave * SK_KB; s0 < nks; s0 += NW * SK_KB) {
+        bf16x8 af[SK_KB][4], bf[SK_KB][4];
+#pragma unroll
+        for (int t = 0; t < SK_KB; ++t) {
+            const int k = (s0 + t < nks ? s0 + t : nks - 1) * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { af[t][i] = *(const bf16x8*)(ap[i] + k); bf[t][i] = *(const bf16x8*)(bp[i] + k); }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // all of the batch's loads issued before the first MFMA waits for one
+#pragma unroll
+        for (int t = 0; t < SK_KB; ++t) {
+            if (s0 + t >= nks) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t][j], af[t][i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(wave * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    // wave w takes rows 16 (w & 3) .. of the tile; with eight waves, waves 4-7 the right half of the columns
+    const int mi = wave & 3;
+    const int m = m0 + 16 * mi + r;
+#pragma unroll
+    for (int jj = 0; jj < 16 / NW; ++jj) {
+        const int j = NW == 8 ? 2 * (wave >> 2) + jj : jj;
+        const int n4 = n0 + 16 * j + 4 * g;
+        f32x4 v = part[(mi * 4 + j) * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) v += part[(ww * 16 + mi * 4 + j) * 64 + lane];
+        if (m >= p.M || n4 >= p.N) continue;
+        const int64_t o = (int64_t)m * p.ldc + n4;
+        if (EPI != VIPANT_EPI_DQUICKGELU_D8 && p.bias != nullptr) v += *(const f32x4*)(p.bias + n4);
+        if (EPI == VIPANT_EPI_BF16) {
+            *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(v);
+        } else if (EPI == VIPANT_EPI_F32) {
+            *(f32x4*)((float*)p.C + o) = v;
+        } else if (EPI == VIPANT_EPI_RESIDUAL_F32) {
+            *(f32x4*)((float*)p.C + o) = v + *(const f32x4*)((const float*)p.aux + o);
+        } else if (EPI == VIPANT_EPI_QUICKGELU_D8) {      // as the big kernel: the gate sees the bf16-rounded pre-activation
+            const bf16x4 ub = f32x4_to_bf16x4(v);
+            f32x4 ge;
+            uint32_t code = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = (float)ub[e];
+                const float sg = quickgelu_gate(u);
+                ge[e] = u * sg;
+                code = gelu_code_pack(sg * (1.0f + 1.702f * u * (1.0f - sg)), e, code);
+            }
+            *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(ge);
+            *(uint32_t*)((uint8_t*)p.aux + o) = code;
+        } else {  // VIPANT_EPI_DQUICKGELU_D8
+            const uint32_t code = *(const uint32_t*)((const uint8_t*)p.aux + o);
+            f32x4 d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = v[e] * gelu_decode((code >> (8 * e)) & 255u);
+            *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(d);
+        }
+    }
+}
+
+template <int EPI, int NW>
+int32_t launch_skinny_nw(const GemmNT& p, hipStream_t stream) {
+    constexpr int lds = NW * 16 * 64 * 16;
+    static bool configured = false;
+    if (!configured) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const unsigned grid = (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64));
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW>), dim3(grid), dim3(NW * 64), lds, stream, p);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+template <int EPI>
+int32_t launch_skinny(const GemmNT& p, hipStream_t stream) {
+    return launch_skinny_nw<EPI, 4>(p, stream);
+}
+
 extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, void* C,
                                   int64_t ldc, const float* bias, void* aux, float alpha, int64_t M, int64_t N,
                                   int64_t K, int32_t epilogue, void* stream) {
@@ -911,11 +1025,32 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
                    "gemm_nt: operands must be 16-byte aligned");
     VIPANT_REQUIRE(256 * lda * 2 < (1ll << 31) && 256 * ldb * 2 < (1ll << 31), VIPANT_EBADSHAPE,
                    "gemm_nt: leading dimension too large");
-    static const int dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
+    const char* var = getenv("VIPANT_GEMM_VARIANT");       // read per call: tests and A/B scripts switch it inside one process
+    const int dbg = var ? atoi(var) : 0;
     GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, alpha, dbg, nullptr, nullptr, 0, nullptr};
     hipStream_t s = (hipStream_t)stream;
     const bool staged = (N % 8 == 0) && (ldc % 8 == 0) && !(dbg & 2);
     const bool pp = staged && K >= 128 && !(dbg & 16);
+    const bool few_rows = (epilogue & VIPANT_EPI_FEW_ROWS) != 0;
+    epilogue &= ~VIPANT_EPI_FEW_ROWS;
+    if (few_rows && !(dbg & 2097152)) {        // bit 21 of VIPANT_GEMM_VARIANT sends them through the 256 x 256 kernels again (A/B)
+        switch (epilogue) {
+            case VIPANT_EPI_BF16: return launch_skinny<VIPANT_EPI_BF16>(p, s);
+            case VIPANT_EPI_F32: return launch_skinny<VIPANT_EPI_F32>(p, s);
+            case VIPANT_EPI_RESIDUAL_F32:
+                VIPANT_REQUIRE(aux != nullptr, VIPANT_EBADSHAPE, "gemm_nt: residual epilogue needs aux");
+                return launch_skinny<VIPANT_EPI_RESIDUAL_F32>(p, s);
+            case VIPANT_EPI_QUICKGELU_D8:
+            case VIPANT_EPI_DQUICKGELU_D8:
+                VIPANT_REQUIRE(aux != nullptr && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
+                               "gemm_nt: the 8-bit QuickGELU' epilogues need aux (the code matrix), 16-byte aligned");
+                return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_skinny<VIPANT_EPI_QUICKGELU_D8>(p, s)
+                                                            : launch_skinny<VIPANT_EPI_DQUICKGELU_D8>(p, s);
+            default:
+                vipant_set_error("gemm_nt: VIPANT_EPI_FEW_ROWS with epilogue %d (BF16, F32, RESIDUAL_F32 and the two _D8 epilogues only)", epilogue);
+                return VIPANT_EBADSHAPE;
+        }
+    }
     switch (epilogue) {
         case VIPANT_EPI_BF16:
             if (pp) return launch_pp<VIPANT_EPI_BF16>(p, s);

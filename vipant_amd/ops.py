@@ -74,8 +74,9 @@ def scratch(name: str, nbytes: int, device) -> torch.Tensor:
 
 # --------------------------------------------------------------------------------------- raw ops
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux=None, epi: int = EPI_BF16,
-            alpha: float = 1.0):
-    """c[M,N] = a[M,K] @ b[N,K]^T with the epilogue `epi` (see include/vipant_hip.h)."""
+            alpha: float = 1.0, few_rows: bool = False):
+    """c[M,N] = a[M,K] @ b[N,K]^T with the epilogue `epi` (see include/vipant_hip.h).  `few_rows`: the rows are one per item of a
+    batch (VIPANT_EPI_FEW_ROWS: small tiles, K split over a workgroup's waves)."""
     _need(a, BF16, "gemm_nt.a"); _need(b, BF16, "gemm_nt.b")
     M, K = a.shape
     N = b.shape[0]
@@ -89,7 +90,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, *, bias=None, aux
     else:
         probe = None
     call("vipant_gemm_nt", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
-         _ptr(bias), _ptr(aux), float(alpha), M, N, K, epi, _stream())
+         _ptr(bias), _ptr(aux), float(alpha), M, N, K, epi | (_ffi.EPI_FEW_ROWS if few_rows else 0), _stream())
     if probe is not None:
         e1.record()
         probe["events"].append((e0, e1))
@@ -574,7 +575,7 @@ class BackboneFn(torch.autograd.Function):
                 if xs is not None:
                     x = xs
                 h1_r = gather_rows(h1, ridx, batch, S)
-                q_r = gemm_nt(h1_r, wqkv_b[:D], newr(D), bias=bqkv[:D], epi=EPI_BF16)     # Q of the read-out rows
+                q_r = gemm_nt(h1_r, wqkv_b[:D], newr(D), bias=bqkv[:D], epi=EPI_BF16, few_rows=True)     # Q of the read-out rows
                 probs = torch.empty((batch, H, S), dtype=F32, device=dev)
                 if ctx_alg:
                     # one query per (item, head): the key projection moves to the query (qk_h = W_k,h^T q_h, the key bias drops out
@@ -595,7 +596,7 @@ class BackboneFn(torch.autograd.Function):
                     o_r = newr(D)
                     call("vipant_mha_rows_fwd", q_r.data_ptr(), qkv.data_ptr(), _ptr(ridx), o_r.data_ptr(), probs.data_ptr(), batch, S,
                          H, int(causal), st)
-                y1_r = gemm_nt(o_r, wo_b, newr(D), bias=bo, epi=EPI_BF16)
+                y1_r = gemm_nt(o_r, wo_b, newr(D), bias=bo, epi=EPI_BF16, few_rows=True)
                 x_r = gather_rows(x, ridx, batch, S)
                 # the read-out rows' stream stays fp32 from here, and c_proj adds it in its epilogue: the rows the features are
                 # read from skip the two roundings (fp16 stream, bf16 branch output) the full block would give them
@@ -604,8 +605,8 @@ class BackboneFn(torch.autograd.Function):
                 call("vipant_layernorm_fwd_e4m3", x_r.data_ptr(), D, ln2w.data_ptr(), ln2b.data_ptr(), h2_r.data_ptr(), None,
                      mean2_r.data_ptr(), rstd2_r.data_ptr(), batch, D, y1_r.data_ptr(), x1_r.data_ptr(), None, None,
                      _ffi.STREAM_IN_F16 if x_r.dtype == F16 else 0, st)
-                gemm_nt(h2_r, wfc_b, g_r, bias=bfc, aux=u_r, epi=EPI_QUICKGELU_D8)
-                out_r = gemm_nt(g_r, wpr_b, newr(D, F32), bias=bpr, aux=x1_r, epi=EPI_RESIDUAL_F32)
+                gemm_nt(h2_r, wfc_b, g_r, bias=bfc, aux=u_r, epi=EPI_QUICKGELU_D8, few_rows=True)
+                out_r = gemm_nt(g_r, wpr_b, newr(D, F32), bias=bpr, aux=x1_r, epi=EPI_RESIDUAL_F32, few_rows=True)
                 if train:
                     saved += [x, mean1, rstd1, h1, qkv, q_r, probs, o_r, h1_r, x1_r, mean2_r, rstd2_r, h2_r, u_r, g_r]
                 x, y_prev = out_r, None
@@ -727,9 +728,10 @@ class BackboneFn(torch.autograd.Function):
                      g_r.data_ptr(), h2_r.data_ptr(), x1_r.data_ptr(), mean2_r.data_ptr(), rstd2_r.data_ptr(), ln2w.data_ptr(), None,
                      dxr_b.data_ptr(), du_r.data_ptr(), dh_r.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(),
                      d_ln2w.data_ptr(), d_ln2b.data_ptr(), d_bo.data_ptr(), batch, D, ws.data_ptr(), ws.numel(), None,
-                     _ffi.STREAM_IN_F16 if x1_r.dtype == F16 else 0, st)
-                call("vipant_gemm_bias_residual_bwd_e4m3", dxr_b.data_ptr(), wo_t.data_ptr(), o_r.data_ptr(), do_r.data_ptr(),
-                     d_wo.data_ptr(), batch, D, D, ws.data_ptr(), ws.numel(), None, st)
+                     (_ffi.STREAM_IN_F16 if x1_r.dtype == F16 else 0) | _ffi.STREAM_FEW_ROWS, st)
+                # out_proj backward on the rows (vipant_gemm_bias_residual_bwd's two launches, the first as a few-rows launch)
+                gemm_nt(dxr_b, wo_t, do_r, epi=EPI_BF16, few_rows=True)
+                gemm_tn(dxr_b, o_r, d_wo, ws_name="block_bwd")
                 if ctx.last_ctx:
                     wqkv_b_last = ctx.wqkv_b_last
                     # qkv = [qk | contexts] of the forward.  dctx_h = W_v,h^T do_h; the kernel gives dh of every token and dqk;
@@ -754,7 +756,7 @@ class BackboneFn(torch.autograd.Function):
                     gemm_tn(dqkv[:, D:], h1, d_wqkv[D:], a_colsum=d_bqkv[D:], ws_name="block_bwd")
                     del dqkv
                 # + dq . W_q on the read-out rows
-                dhq = gemm_nt(dq_r, wqkv_t[:, :D], torch.empty((batch, D), dtype=F32, device=dev), epi=EPI_F32)
+                dhq = gemm_nt(dq_r, wqkv_t[:, :D], torch.empty((batch, D), dtype=F32, device=dev), epi=EPI_F32, few_rows=True)
                 call("vipant_add_rows_bf16", dh.data_ptr(), _ptr(ridx), dhq.data_ptr(), 1, batch, S, D, st)
                 gemm_tn(dq_r, h1_r, d_wqkv[:D], a_colsum=d_bqkv[:D], ws_name="block_bwd")
                 # ln_1 backward on every token; the residual gradient of this block exists on the read-out rows only
