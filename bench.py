@@ -29,10 +29,19 @@ DOMINANT_KERNEL = "gemm_nt_pp_kernel<6, 8, 2>"      # c_fc forward + QuickGELU, 
 
 def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=False):
     """L*S*(24 D^2 + 4 S D) + 2 P Kpatch D + 2 D E per sample.  With `running.last_block_rows` the last block
-    is evaluated on the one row per item the read-out takes: its key / value projection sees every token (4 S D^2), everything
-    else one row (24 D^2 - 4 D^2 + 4 S D) -- the work the step then actually needs, and what is counted."""
+    is evaluated on the one row per item the read-out takes, and what is counted is the work the step then actually needs:
+    round-3 form (`VIPANT_LAST_BLOCK_CTX=0`, or a width / length the folded kernels do not take): the key / value projection of
+    every token (4 S D^2) + everything else on one row (20 D^2 + 4 S D); default (key / value projection folded into the query
+    side, csrc/readout_ctx.hip): one row's 24 D^2 (the two folded projections are D x D per item) + scores and contexts against
+    the LayerNorm output, 4 S H D with H = D / 64.  The zeros of the block-sparse head expansion are not counted."""
     full = S * (24 * width * width + 4 * S * width)
-    last = 4 * S * width * width + 20 * width * width + 4 * S * width if (last_block_rows and layers > 0) else full
+    folded = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0" and width in (512, 768, 1024) and S <= 2048
+    if not (last_block_rows and layers > 0):
+        last = full
+    elif folded:
+        last = 24 * width * width + 4 * S * (width // 64) * width
+    else:
+        last = 4 * S * width * width + 20 * width * width + 4 * S * width
     return (layers - 1) * full + last + 2 * P * kpatch * width + 2 * width * embed if layers > 0 else 2 * P * kpatch * width + 2 * width * embed
 
 

@@ -11,9 +11,9 @@
 //     dp_j = dctx_h . h1_j,  delta = dctx_h . ctx_h,  ds_j = p_j (dp_j - delta) / 8,
 //     dh1_j = sum_h p_j,h dctx_h + ds_j,h qk_h        (rank-2H update per token),     dqk_h = sum_j ds_j,h h1_j.
 // Both kernels stream h1 (fwd: read; bwd: read + write dh1) in place of the K / V projection, its dX, its dW and the two one-query
-// kernels.  One workgroup of four waves per item.  The dot products over D (scores, dp) and the rank-2H update that is dh1 run on
-// v_mfma_f32_16x16x32_bf16 with the heads padded to 16; the two sums over tokens (contexts, dqk) are fp32 multiply-adds on the VALU,
-// a wave owning H / 4 heads.
+// kernels.  One workgroup of four waves per item, rounds of 32 tokens staged in LDS by LDS-DMA; every product -- the dot products over
+// D (scores, dp), the two sums over tokens (contexts, dqk: transposed fragments of the staged rows) and the rank-2H update that is
+// dh1 -- runs on v_mfma_f32_16x16x32_bf16 with the heads padded to 16; the softmax statistics are taken one lane per token.
 #include "common.h"
 
 namespace {
@@ -79,171 +79,219 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// The dot products of 16 tokens with all heads on the matrix pipe: acc[head = lane & 15][token 4 (lane >> 4) + i] =
-// sum_k h1[token][k] b[head][k].  A fragments straight from the row-major h1 rows (16 bytes per lane and k-step), B fragments `bq`
-// (the heads' vectors, resident).  `arow`: this lane's token row + 8 (lane >> 4) elements.
-template <int KS>
-__device__ __forceinline__ f32x4 dots_tile(const bf16_t* arow, const bf16x8 (&bq)[KS]) {
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int HALF = KS / 2;
+// ---- LDS images of token rows (the attention kernels' format, csrc/attention.hip): [32 rows x 64 columns] bf16, 128-byte rows, the
+// 16-byte chunk c of row r stored at position c ^ img_swz(r).  A round's 32 token rows of h1 are D / 64 such images side by side.
+// Row fragments (A operand rows = tokens, K = the image's columns) are plain 16-byte reads; transposed fragments (operand rows = the
+// image's COLUMNS, K = its 32 token rows) come from ds_read_b64_tr_b16: both conflict-free under this swizzle.
+__device__ __forceinline__ int img_swz(int r) { return ((r >> 1) & 3) << 1; }
+struct ImgLane {
+    uint32_t row[2];   // row fragment of 16-row tile 0, column step 0 / 1 (32 columns each)
+    uint32_t tr[4];    // transposed fragment, first read, column tile 0..3 (16 columns each)
+};
+__device__ __forceinline__ ImgLane img_lane(int lane) {
+    ImgLane a;
+    const int r = lane & 15, g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
-        bf16x8 af[HALF];
+    for (int ds = 0; ds < 2; ++ds) a.row[ds] = (uint32_t)(r * 128 + (((ds * 4 + g) ^ img_swz(r)) << 4));
+    const int ra = 4 * g + qq;
 #pragma unroll
-        for (int s = 0; s < HALF; ++s) af[s] = *(const bf16x8*)(arow + 32 * (part * HALF + s));
-#pragma unroll
-        for (int s = 0; s < HALF; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bq[part * HALF + s], a, 0, 0, 0);
-    }
+    for (int dt = 0; dt < 4; ++dt) a.tr[dt] = (uint32_t)(ra * 128 + (((2 * dt + (pp >> 1)) ^ img_swz(ra)) << 4) + (pp & 1) * 8);
     return a;
 }
-// the same with the B fragments in LDS (`bqs`: [KS][64 lanes] fragments, this lane's at bqs[64 s])
-template <int KS>
-__device__ __forceinline__ f32x4 dots_tile_lds(const bf16_t* arow, const bf16x8* bqs) {
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int HALF = KS / 2;
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-        bf16x8 af[HALF];
-#pragma unroll
-        for (int s = 0; s < HALF; ++s) af[s] = *(const bf16x8*)(arow + 32 * (part * HALF + s));
-#pragma unroll
-        for (int s = 0; s < HALF; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bqs[64 * (part * HALF + s)], a, 0, 0, 0);
+__device__ __forceinline__ bf16x8 img_row_frag(const char* img, const ImgLane& a, int tile, int ds) {
+    return *(const bf16x8*)(img + a.row[ds] + tile * 2048);
+}
+// operand[row = column 16 dt + (lane & 15) of the image][k-slot (g, e)]: e < 4 -> image row 4 g + e, e >= 4 -> image row 16 + 4 g + (e - 4)
+__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, const ImgLane& a, int dt) {
+    const bf16x4 lo = lds_read_tr16(img + a.tr[dt]);
+    const bf16x4 hi = lds_read_tr16(img + a.tr[dt] + 2048);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// the other operand of such a product, from a [16 heads][32 tokens] bf16 array: the same token order
+__device__ __forceinline__ bf16x8 head_token_frag(const bf16_t* buf, int r, int g) {
+    const bf16x4 lo = *(const bf16x4*)(buf + r * 32 + 4 * g);
+    const bf16x4 hi = *(const bf16x4*)(buf + r * 32 + 16 + 4 * g);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// rows j0 .. j0 + 31 of an item (rows past the end read as zeros through the buffer descriptor) -> NI images, by LDS-DMA
+template <int NI>
+__device__ __forceinline__ void fill_images(char* imgs, __amdgpu_buffer_rsrc_t rs, int j0, int wave, int lane) {
+    for (int q = wave; q < NI * 4; q += 4) {
+        const int img = q >> 2, blk = q & 3;
+        const int r = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ img_swz(r);
+        lds_dma16(rs, imgs + img * 4096 + blk * 1024, (uint32_t)(j0 + r) * (NI * 128) + (uint32_t)(img * 128 + c * 16), 0);
     }
-    return a;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// (A) of both kernels: [32 tokens] x [16 heads] dot products over D: wave w takes token tile w & 1 and the K half w >> 1, the two
+// halves are added by the reader.  part: [2 halves][16 heads][32 tokens] fp32; bq: the heads' vectors as B fragments, this wave's K half
+// (a register array indexed by the wave's number would live in scratch memory).
+template <int NI>
+__device__ __forceinline__ void dots_round(const char* imgs, const ImgLane& a, const bf16x8 (&bq)[NI], float* part, int wave, int r,
+                                           int g) {
+    const int tile = wave & 1, kh = wave >> 1;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ii = 0; ii < NI / 2; ++ii) {
+        const int img = kh * (NI / 2) + ii;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(imgs + img * 4096, a, tile, ds), bq[2 * ii + ds], acc, 0, 0, 0);
+    }
+    *(f32x4*)(part + (kh * 16 + r) * 32 + 16 * tile + 4 * g) = acc;
 }
 
 // ctx[item, h, :] = sum_j softmax_j(qk[item, h, :] . h1[item, j, :] / 8) h1[item, j, :];  probs[item, h, j] = that softmax (fp32).
-// One workgroup per item, rounds of 64 tokens: (A) wave w takes the scores of tokens 16 w .. 16 w + 15 of the round against ALL heads
-// on the matrix pipe and leaves them in LDS; (B) wave w owns heads HPW w .. HPW w + HPW - 1: one lane per token of the round takes the
-// round's maximum, rescales if it moved, exponentiates; (C) the weighted sum of the 64 rows for the wave's heads on the VALU
-// (2 D multiply-adds per head and token, the weights broadcast from LDS).  Raw scores wait in LDS until maximum and sum are final.
-template <int EPL, int HPW, int MINB>
+// One workgroup per item, rounds of 32 tokens staged in LDS as images: (A) the scores of the round against ALL heads (padded to 16)
+// on the matrix pipe; (B) wave w owns heads HPW w ..: one lane per token takes the round's maximum, the rescale factor and the
+// exponentials, left in LDS as bf16 P[head][token]; (C) ctx^T[columns x heads] += h1^T[columns x tokens] . P^T[tokens x heads], wave w
+// owning columns D / 4 * w ..: transposed fragments of the images.  Raw scores wait in LDS until maximum and sum are final.
+template <int NI, int HPW, int MINB>
 __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ h1,
                                                                  const int64_t* __restrict__ idx, bf16_t* __restrict__ ctx,
                                                                  float* __restrict__ probs, int S, int causal) {
-    constexpr int D = EPL * 64, NH = 4 * HPW, KS = D / 32, PF = 8;
-    extern __shared__ float sm[];     // [NH][Sp] raw scores (exp2 domain) | [4 waves][HPW][64] weights of the round | B fragments
+    constexpr int D = NI * 64, NH = 4 * HPW, IPW = NI / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* imgs = smem;                                          // NI x 4 KiB
+    float* part = (float*)(smem + NI * 4096);                   // [2][16][32] fp32
+    bf16_t* pbuf = (bf16_t*)(part + 2 * 16 * 32);               // [16][32] bf16
+    float* fbuf = (float*)(pbuf + 16 * 32);                     // [16] rescale factors of the round, then 1 / sum
+    float* sc = fbuf + 16;                                      // [NH][Sp] raw scores (exp2 domain)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const int item = blockIdx.x;
     const int nkeys = key_limit(idx, item, S, causal);
-    const int Sp = (S + 63) & ~63;
-    float* sc = sm;
-    float* pp = sm + NH * Sp + wave * HPW * 64;
-    bf16x8* bqs = (bf16x8*)(sm + NH * Sp + 4 * HPW * 64) + lane;     // [KS][64]: the heads' vectors as B fragments, lane-linear
+    const int Sp = (S + 31) & ~31;
     const int64_t head0 = (int64_t)item * NH + HPW * wave;
     const bf16_t* rows = h1 + (int64_t)item * S * D;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(rows, (uint32_t)S * D * 2);
+    const ImgLane a = img_lane(lane);
+    bf16x8 bq[NI];
     {
-        const bf16_t* qrow = qk + ((int64_t)item * NH + (r < NH ? r : 0)) * D + 8 * g;
-        for (int s = wave; s < KS; s += 4) bqs[64 * s] = r < NH ? *(const bf16x8*)(qrow + 32 * s) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    __syncthreads();
-    float acc[HPW][EPL], m[HPW], lsum[HPW];
+        const bf16_t* qrow = qk + ((int64_t)item * NH + (r < NH ? r : 0)) * D + (wave >> 1) * (D / 2) + 8 * g;
 #pragma unroll
-    for (int h = 0; h < HPW; ++h) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[h][e] = 0.f;
-        m[h] = -INFINITY; lsum[h] = 0.f;
-    }
-    RawRow<EPL> nxt[PF];                                // the rows of the next PF tokens, in flight while the current PF are used
-#pragma unroll
-    for (int t = 0; t < PF; ++t) nxt[t] = load_raw<EPL>(rows + (int64_t)(t < S ? t : S - 1) * D, lane);
-    for (int j0 = 0; j0 < nkeys; j0 += 64) {
-        {   // (A)
-            const int tok = j0 + 16 * wave + r;
-            const f32x4 a = dots_tile_lds<KS>(rows + (int64_t)(tok < S ? tok : S - 1) * D + 8 * g, bqs);
-            if (r < NH) *(f32x4*)(sc + r * Sp + j0 + 16 * wave + 4 * g) = a * (0.125f * LOG2E_);
+        for (int s = 0; s < NI; ++s) {
+            bq[s] = *(const bf16x8*)(qrow + 32 * s);
+            if (r >= NH) bq[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+    }
+    for (int i = threadIdx.x; i < 16 * 32 / 2; i += 256) ((uint32_t*)pbuf)[i] = 0u;        // heads NH .. 15 stay zero
+    if (threadIdx.x < 16) fbuf[threadIdx.x] = 0.f;
+    f32x4 acc[IPW][4];
+#pragma unroll
+    for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[ii][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[HPW], lsum[HPW];
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) { m[h] = -INFINITY; lsum[h] = 0.f; }
+    for (int j0 = 0; j0 < nkeys; j0 += 32) {
+        fill_images<NI>(imgs, rs, j0, wave, lane);
+        __syncthreads();
+        dots_round<NI>(imgs, a, bq, part, wave, r, g);                                        // (A)
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < HPW; ++h) {   // (B)
-            const int j = j0 + lane;
-            const float sv = j < nkeys ? sc[(HPW * wave + h) * Sp + j] : -INFINITY;
-            const float rmax = wave_max_dpp(sv);
-            if (rmax > m[h]) {                          // wave-uniform
-                const float f = __builtin_amdgcn_exp2f(m[h] - rmax);
-                lsum[h] *= f;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[h][e] *= f;
-                m[h] = rmax;
+        for (int h = 0; h < HPW; ++h) {                                                       // (B)
+            const int hg = HPW * wave + h, j = j0 + lane;
+            const bool on = lane < 32 && j < nkeys;
+            const float sv = on ? (part[hg * 32 + (lane & 31)] + part[(16 + hg) * 32 + (lane & 31)]) * (0.125f * LOG2E_) : -INFINITY;
+            const float mn = fmaxf(m[h], wave_max_dpp(sv));
+            const float f = __builtin_amdgcn_exp2f(m[h] - mn);
+            const float pj = __builtin_amdgcn_exp2f(sv - mn);
+            lsum[h] = lsum[h] * f + pj;                 // per-lane share of the sum; added up across lanes at the end
+            m[h] = mn;
+            if (lane < 32) {
+                pbuf[hg * 32 + lane] = (bf16_t)pj;
+                sc[hg * Sp + j] = sv;
             }
-            const float pj = __builtin_amdgcn_exp2f(sv - m[h]);
-            lsum[h] += pj;                              // per-lane share of the sum; added up across lanes at the end
-            pp[h * 64 + lane] = pj;
+            if (lane == 0) fbuf[hg] = f;
         }
-        for (int t0 = 0; t0 < 64 && j0 + t0 < nkeys; t0 += PF) {   // (C)
-            f32x4 pw[HPW][PF / 4];
+        __syncthreads();
+        {                                                                                     // (C)
+            const float f = fbuf[r];
+            const bf16x8 bp = head_token_frag(pbuf, r, g);
 #pragma unroll
-            for (int h = 0; h < HPW; ++h)
+            for (int ii = 0; ii < IPW; ++ii)
 #pragma unroll
-                for (int u = 0; u < PF / 4; ++u) pw[h][u] = *(const f32x4*)(pp + h * 64 + t0 + 4 * u);
-#pragma unroll
-            for (int t = 0; t < PF; ++t) {
-                float x[EPL];
-                widen<EPL>(nxt[t], x);
-                const int jn = j0 + t0 + t + PF;
-                nxt[t] = load_raw<EPL>(rows + (int64_t)(jn < S ? jn : S - 1) * D, lane);
-#pragma unroll
-                for (int h = 0; h < HPW; ++h)
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) acc[h][e] = __builtin_fmaf(pw[h][t >> 2][t & 3], x[e], acc[h][e]);
-            }
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[ii][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(imgs + (IPW * wave + ii) * 4096, a, dt), bp,
+                                                                          acc[ii][dt] * f, 0, 0, 0);
         }
+        __syncthreads();
+    }
+    float inv[HPW];
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        inv[h] = 1.0f / wave_sum_dpp(lsum[h]);
+        if (lane == 0) fbuf[HPW * wave + h] = inv[h];
+    }
+    __syncthreads();
+    if (r < NH) {       // lane: head r, columns 64 img + 16 dt + 4 g .. + 3
+        const float iv = fbuf[r];
+        bf16_t* orow = ctx + ((int64_t)item * NH + r) * D + 4 * g;
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = f32x4_to_bf16x4(acc[ii][dt] * iv);
     }
 #pragma unroll
     for (int h = 0; h < HPW; ++h) {
-        const float inv = 1.0f / wave_sum_dpp(lsum[h]);
-        float o[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] = acc[h][e] * inv;
-        store_row<EPL>(ctx + (head0 + h) * D, lane, o);
         float* pout = probs + (head0 + h) * S;
         for (int j = lane; j < S; j += 64)
-            pout[j] = j < nkeys ? __builtin_amdgcn_exp2f(sc[(HPW * wave + h) * Sp + j] - m[h]) * inv : 0.f;
+            pout[j] = j < nkeys ? __builtin_amdgcn_exp2f(sc[(HPW * wave + h) * Sp + j] - m[h]) * inv[h] : 0.f;
     }
 }
 
 // dh1[item, j, :] = sum_h p_j,h dctx_h + ds_j,h qk_h;  dqk[item, h, :] = sum_j ds_j,h h1_j;  ds_j,h = p_j,h (dctx_h . h1_j - dctx_h . ctx_h) / 8.
-// Rounds of 64 tokens as in the forward: (A) dctx_h . h1_j for 16 tokens x all heads per wave on the matrix pipe; (B) one lane per
-// token: ds for the wave's heads, left in LDS as fp32 (for C) and, with p, as the bf16 row [p_0 .. p_15 | ds_0 .. ds_15] of the
-// token (for D); (C) dqk of the wave's heads on the VALU; (D) dh1 of the wave's 16 tokens as ONE matrix product per 16 columns:
-// (dh1 tile)^T [16 columns x 16 tokens] = [dctx | qk]^T [16 columns x 32] . [p | ds]^T [32 x 16 tokens], the left operand resident in
-// LDS for the item ([D][32] bf16, 16-byte chunks XOR-ed with (column >> 2) & 3: conflict-free 128-bit reads).
-template <int EPL, int HPW, int MINB>
+// Rounds of 32 tokens as in the forward: (A) dctx_h . h1_j on the matrix pipe; (B) one lane per token: ds for the wave's heads, left in
+// LDS as bf16 dS[head][token] (for C) and, with p, as the token's row [p_0 .. p_15 | ds_0 .. ds_15] (for D); (C) dqk^T[columns x heads]
+// += h1^T . dS^T from transposed image fragments, wave w owning columns D / 4 * w ..; (D) dh1 of the round as ONE product per 16 tokens
+// x 16 columns: (dh1 tile)^T = [dctx | qk]^T [16 columns x 32] . [p | ds]^T [32 x 16 tokens] -- the left operand, for the wave's D / 4
+// columns, is resident in registers (built once per item through the image area), the result leaves as 16-byte stores.
+template <int NI, int HPW, int MINB>
 __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ dctx,
                                                                  const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ h1,
                                                                  const int64_t* __restrict__ idx, const float* __restrict__ probs,
                                                                  bf16_t* __restrict__ dh1, bf16_t* __restrict__ dqk, int S, int causal) {
-    constexpr int D = EPL * 64, NH = 4 * HPW, KS = D / 32, PF = EPL <= 8 ? 8 : 4;
-    extern __shared__ float sm[];
-    bf16_t* dcq = (bf16_t*)sm;                          // [D][32]: 64 D bytes
-    bf16_t* pds = dcq + D * 32;                         // [64 tokens][32]: 4 KiB
-    float* dpb = (float*)(pds + 64 * 32);               // [16 heads][64 tokens] fp32: 4 KiB
+    constexpr int D = NI * 64, NH = 4 * HPW, IPW = NI / 4, CT = NI, EPL = NI;     // CT: 16-column tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* imgs = smem;                                          // NI x 4 KiB (first: [D][32] bf16, the item's [dctx | qk]^T)
+    float* part = (float*)(smem + NI * 4096);                   // [2][16][32] fp32
+    bf16_t* dsbuf = (bf16_t*)(part + 2 * 16 * 32);              // [16][32] bf16: dS[head][token]
+    bf16_t* pds = dsbuf + 16 * 32;                              // [32 tokens][32]: p of 16 heads | ds of 16 heads
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
-    float* dsb = dpb + 16 * 64 + wave * HPW * 64;       // [4 waves][HPW][64] fp32
     const int item = blockIdx.x;
     const int nkeys = key_limit(idx, item, S, causal);
     const int64_t head0 = (int64_t)item * NH + HPW * wave;
     const bf16_t* rows = h1 + (int64_t)item * S * D;
     bf16_t* drows = dh1 + (int64_t)item * S * D;
-    // the item's [dctx | qk]^T and the zero padding of the token rows
-    for (int i = threadIdx.x; i < (D * 32 + 64 * 32) / 8; i += 256) ((u32x4*)dcq)[i] = u32x4{0u, 0u, 0u, 0u};
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(rows, (uint32_t)S * D * 2);
+    const ImgLane a = img_lane(lane);
+    // the item's [dctx | qk]^T through the image area into registers; zero padding of the small arrays
+    bf16_t* dcq = (bf16_t*)imgs;
+    for (int i = threadIdx.x; i < (D * 32 + 2 * 16 * 32 * 2 + 16 * 32 + 32 * 32) / 8; i += 256) ((u32x4*)smem)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    for (int i = threadIdx.x; i < NH * D; i += 256) {
-        const int hh = i / D, n = i - hh * D;
-        const int sw = (n >> 2) & 3;
-        dcq[n * 32 + 8 * ((hh >> 3) ^ sw) + (hh & 7)] = dctx[((int64_t)item * NH + hh) * D + n];
-        dcq[n * 32 + 8 * ((2 + (hh >> 3)) ^ sw) + (hh & 7)] = qk[((int64_t)item * NH + hh) * D + n];
-    }
-    bf16x8 bq[KS];
-    {
-        const bf16_t* qrow = dctx + ((int64_t)item * NH + (r < NH ? r : 0)) * D + 8 * g;
+    for (int i = threadIdx.x; i < NH * (D / 8); i += 256) {      // 8 columns of one head per thread
+        const int hh = i / (D / 8), n8 = (i - hh * (D / 8)) * 8;
+        const bf16x8 vd = *(const bf16x8*)(dctx + ((int64_t)item * NH + hh) * D + n8);
+        const bf16x8 vq = *(const bf16x8*)(qk + ((int64_t)item * NH + hh) * D + n8);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int e = 0; e < 8; ++e) {
+            const int n = n8 + e, sw = (n >> 2) & 3;
+            dcq[n * 32 + 8 * ((hh >> 3) ^ sw) + (hh & 7)] = vd[e];
+            dcq[n * 32 + 8 * ((2 + (hh >> 3)) ^ sw) + (hh & 7)] = vq[e];
+        }
+    }
+    bf16x8 bq[NI];
+    {
+        const bf16_t* qrow = dctx + ((int64_t)item * NH + (r < NH ? r : 0)) * D + (wave >> 1) * (D / 2) + 8 * g;
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
             bq[s] = *(const bf16x8*)(qrow + 32 * s);
             if (r >= NH) bq[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    float acc[HPW][EPL], delta[HPW];
+    float delta[HPW];
 #pragma unroll
     for (int h = 0; h < HPW; ++h) {
         float dc[EPL], c[EPL];
@@ -251,67 +299,76 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
         load_row<EPL>(ctx + (head0 + h) * D, lane, c);
         float d = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { d = __builtin_fmaf(dc[e], c[e], d); acc[h][e] = 0.f; }
+        for (int e = 0; e < EPL; ++e) d = __builtin_fmaf(dc[e], c[e], d);
         delta[h] = wave_sum_dpp(d);
     }
-    RawRow<EPL> nxt[PF];                                // the rows of the next PF tokens, in flight while the current PF are used
-#pragma unroll
-    for (int t = 0; t < PF; ++t) nxt[t] = load_raw<EPL>(rows + (int64_t)(t < S ? t : S - 1) * D, lane);
     __syncthreads();
-    for (int j0 = 0; j0 < S; j0 += 64) {
-        const bool live = j0 < nkeys;                   // rounds behind a causal limit: zeros for dh1, nothing else
-        if (live) {   // (A)
-            const int tok = j0 + 16 * wave + r;
-            const f32x4 a = dots_tile<KS>(rows + (int64_t)(tok < S ? tok : S - 1) * D + 8 * g, bq);
-            *(f32x4*)(dpb + r * 64 + 16 * wave + 4 * g) = a;
-        }
-        __syncthreads();
+    // operand row m = 4 g' + i' of the product (pair p, half c) is column 32 p + 8 g' + 4 c + i' of the wave's share: a lane's results
+    // of the two halves are then 8 consecutive columns of its token, one 16-byte store
+    bf16x8 aq[CT];
 #pragma unroll
-        for (int h = 0; h < HPW; ++h) {   // (B)
-            const int j = j0 + lane, hg = HPW * wave + h;
-            const float pj = j < nkeys ? probs[(head0 + h) * S + j] : 0.f;
-            const float ds = live ? pj * (dpb[hg * 64 + lane] - delta[h]) * 0.125f : 0.f;
-            dsb[h * 64 + lane] = ds;
-            const int sw = (lane >> 2) & 3;
-            pds[lane * 32 + 8 * ((hg >> 3) ^ sw) + (hg & 7)] = (bf16_t)pj;
-            pds[lane * 32 + 8 * ((2 + (hg >> 3)) ^ sw) + (hg & 7)] = (bf16_t)ds;
-        }
-        __syncthreads();
-        if (live) {
-            for (int t0 = 0; t0 < 64 && j0 + t0 < nkeys; t0 += PF) {   // (C)
-                f32x4 dw[HPW][PF / 4];
-#pragma unroll
-                for (int h = 0; h < HPW; ++h)
-#pragma unroll
-                    for (int u = 0; u < PF / 4; ++u) dw[h][u] = *(const f32x4*)(dsb + h * 64 + t0 + 4 * u);
-#pragma unroll
-                for (int t = 0; t < PF; ++t) {
-                    float x[EPL];
-                    widen<EPL>(nxt[t], x);
-                    const int jn = j0 + t0 + t + PF;
-                    nxt[t] = load_raw<EPL>(rows + (int64_t)(jn < S ? jn : S - 1) * D, lane);
-#pragma unroll
-                    for (int h = 0; h < HPW; ++h)
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) acc[h][e] = __builtin_fmaf(dw[h][t >> 2][t & 3], x[e], acc[h][e]);
-                }
-            }
-        }
-        {   // (D)
-            const int tl = 16 * wave + r, tok = j0 + tl;
-            const bf16x8 bt = *(const bf16x8*)(pds + tl * 32 + 8 * (g ^ ((tl >> 2) & 3)));
-            bf16_t* orow = drows + (int64_t)tok * D + 4 * g;
-#pragma unroll 8
-            for (int mt = 0; mt < D / 16; ++mt) {
-                const int n = 16 * mt + r;
-                const bf16x8 at = *(const bf16x8*)(dcq + n * 32 + 8 * (g ^ ((n >> 2) & 3)));
-                const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                if (tok < S) *(bf16x4*)(orow + 16 * mt) = f32x4_to_bf16x4(c);
-            }
-        }
+    for (int ct = 0; ct < CT; ++ct) {
+        const int n = 16 * CT * wave + 32 * (ct >> 1) + 8 * (r >> 2) + 4 * (ct & 1) + (r & 3);
+        aq[ct] = *(const bf16x8*)(dcq + n * 32 + 8 * (g ^ ((n >> 2) & 3)));
     }
+    f32x4 acc[IPW][4];
 #pragma unroll
-    for (int h = 0; h < HPW; ++h) store_row<EPL>(dqk + (head0 + h) * D, lane, acc[h]);
+    for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[ii][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int j0 = 0; j0 < S; j0 += 32) {
+        const bool live = j0 < nkeys;                   // rounds behind a causal limit: zeros for dh1, nothing else
+        float pj[HPW];
+#pragma unroll
+        for (int h = 0; h < HPW; ++h) pj[h] = (lane < 32 && j0 + lane < nkeys) ? probs[(head0 + h) * S + j0 + lane] : 0.f;
+        if (live) fill_images<NI>(imgs, rs, j0, wave, lane);
+        __syncthreads();
+        if (live) dots_round<NI>(imgs, a, bq, part, wave, r, g);                                // (A)
+        __syncthreads();
+        if (lane < 32) {                                                                      // (B)
+            const int sw = (lane >> 2) & 3;
+#pragma unroll
+            for (int h = 0; h < HPW; ++h) {
+                const int hg = HPW * wave + h;
+                const float ds = live ? pj[h] * (part[hg * 32 + lane] + part[(16 + hg) * 32 + lane] - delta[h]) * 0.125f : 0.f;
+                dsbuf[hg * 32 + lane] = (bf16_t)ds;
+                pds[lane * 32 + 8 * ((hg >> 3) ^ sw) + (hg & 7)] = (bf16_t)pj[h];
+                pds[lane * 32 + 8 * ((2 + (hg >> 3)) ^ sw) + (hg & 7)] = (bf16_t)ds;
+            }
+        }
+        __syncthreads();
+        if (live) {                                                                           // (C)
+            const bf16x8 bd = head_token_frag(dsbuf, r, g);
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    acc[ii][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(imgs + (IPW * wave + ii) * 4096, a, dt), bd,
+                                                                          acc[ii][dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {                                                // (D)
+            const int tl = 16 * tile + r, tok = j0 + tl;
+            const bf16x8 bt = *(const bf16x8*)(pds + tl * 32 + 8 * (g ^ ((tl >> 2) & 3)));
+            bf16_t* orow = drows + (int64_t)tok * D + 16 * CT * wave + 8 * g;
+#pragma unroll
+            for (int pr = 0; pr < CT / 2; ++pr) {
+                const f32x4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[2 * pr], bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[2 * pr + 1], bt, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const bf16x4 lo = f32x4_to_bf16x4(c0), hi = f32x4_to_bf16x4(c1);
+                if (tok < S) *(bf16x8*)(orow + 32 * pr) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+        __syncthreads();
+    }
+    if (r < NH) {
+        bf16_t* orow = dqk + ((int64_t)item * NH + r) * D + 4 * g;
+#pragma unroll
+        for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = f32x4_to_bf16x4(acc[ii][dt]);
+    }
 }
 
 // out[(i, h), :] = 0 except columns 64 h .. 64 h + 63 = rows[i, 64 h ..]: the `batch` rows as block-sparse [batch * H, D] operand
@@ -351,7 +408,7 @@ int32_t check_ctx(int64_t batch, int64_t S, int64_t H) {
 template <int EPL, int HPW, int MINB>
 int32_t launch_fwd(const bf16_t* qk, const bf16_t* h1, const int64_t* idx, bf16_t* ctx, float* probs, int batch, int S, int causal,
                    hipStream_t st) {
-    const int lds = (4 * HPW * ((S + 63) & ~63) + 4 * HPW * 64) * (int)sizeof(float) + EPL * 2 * 64 * 16;
+    const int lds = EPL * 4096 + 4096 + 1024 + 64 + 4 * HPW * ((S + 31) & ~31) * (int)sizeof(float);
     static int configured = 0;
     if (lds > configured) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_fwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -365,7 +422,7 @@ int32_t launch_fwd(const bf16_t* qk, const bf16_t* h1, const int64_t* idx, bf16_
 template <int EPL, int HPW, int MINB>
 int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, const bf16_t* h1, const int64_t* idx, const float* probs,
                    bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, hipStream_t st) {
-    constexpr int lds = EPL * 64 * 64 + 64 * 64 + 16 * 64 * 4 + 4 * HPW * 64 * 4;
+    constexpr int lds = EPL * 4096 + 4096 + 1024 + 2048;
     static bool configured = false;
     if (!configured) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_bwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
