@@ -1581,11 +1581,10 @@ int attn_waves() {
 template <int NT, bool CAUSAL, int NW, int EDGE>
 int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = NT * 16 * 128 * 2;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
     }
     hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
     VIPANT_LAUNCH_CHECK();
@@ -1596,13 +1595,12 @@ template <int NT, bool CAUSAL, int NW, int EDGE>
 int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
     constexpr int lds_a = NT * 16 * 128 * 2;
     constexpr int lds_b = NT * 16 * 128 * 2 + NT * 16 * 8;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dq_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
-        configured = true;
     }
     hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds_a, s, a);
     VIPANT_LAUNCH_CHECK();
@@ -1614,10 +1612,9 @@ int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
 template <int NT>
 int32_t launch_bwd1(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = NT * 8192;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
     }
     static int cus = 0;                              // one persistent workgroup per CU (all 160 KiB of LDS)
     if (!cus) {
@@ -1636,14 +1633,13 @@ int32_t launch_bwd1(const MhaArgs& a, hipStream_t s) {
 template <int NT>
 int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024;
-    static bool configured = false;
+    static DeviceOnce once;
     static int cus = 0;
-    if (!configured) {
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         int dev = 0;
         VIPANT_HIP_TRY(hipGetDevice(&dev));
         VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        configured = true;
     }
     const int nprob = a.batch * a.H;
     hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);

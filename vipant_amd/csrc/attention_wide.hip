@@ -445,10 +445,9 @@ __global__ __launch_bounds__(256, 1) void mha_fwd_wide_kernel(MhaArgs p) {
 template <int NT>
 int32_t launch_fwd_wide_nt(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = 2 * NT * 32 * 128 * 2;        // two image sets
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_wide_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
         if (getenv("VIPANT_ATTN_DEBUG")) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)mha_fwd_wide_kernel<NT>, 256, lds);
@@ -934,14 +933,13 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_wide_kernel(MhaArgs p) {
 
 int32_t launch_bwd_wide_impl(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = 2 * 320 * 128 + 2 * 320 * 64 + 4 * 8192 + 256 + 4096 + 1024;
-    static bool configured = false;
+    static DeviceOnce once;
     static int cus = 0;
-    if (!configured) {
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         int dev = 0;
         VIPANT_HIP_TRY(hipGetDevice(&dev));
         VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        configured = true;
     }
     const int nprob = a.batch * a.H;
     hipLaunchKernelGGL(mha_bwd_wide_kernel, dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);

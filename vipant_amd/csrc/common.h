@@ -50,6 +50,30 @@ void vipant_set_error(const char* fmt, ...);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// One-time set-up of a launcher (the dynamic-LDS opt-in of its kernels, hipFuncSetAttribute) is a property of the DEVICE, not of the
+// process: bit d of the launcher's mask = done on device d (one process per GPU is how the package runs, but nothing here may
+// break the day one process drives two).  Races between host threads are benign: the set-up is idempotent.
+struct DeviceOnce { uint64_t mask[2] = {0, 0}; };
+static inline bool first_on_device(DeviceOnce& o) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    uint64_t& m = o.mask[(dev >> 6) & 1];
+    const uint64_t bit = 1ull << (dev & 63);
+    if (m & bit) return false;
+    m |= bit;
+    return true;
+}
+// the same for a launcher whose LDS request grows with the problem: true when `bytes` exceeds what this device was set up for
+struct DeviceMax { int v[128] = {}; };
+static inline bool raise_on_device(DeviceMax& o, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    int& cur = o.v[dev & 127];
+    if (bytes <= cur) return false;
+    cur = bytes;
+    return true;
+}
+
 // ---- device helpers -----------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 

@@ -837,11 +837,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 
 template <int EPI, int VAR, int ES = 2>
 int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-        configured = true;
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
@@ -869,11 +868,10 @@ int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
 
 template <int EPI>
 int32_t launch_persistent(const GemmNT& p, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        configured = true;
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
@@ -884,11 +882,10 @@ int32_t launch_persistent(const GemmNT& p, hipStream_t stream) {
 
 template <int EPI>
 int32_t launch(const GemmNT& p, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        configured = true;
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, stream, p);
@@ -997,10 +994,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
 template <int EPI, int NW>
 int32_t launch_skinny_nw(const GemmNT& p, hipStream_t stream) {
     constexpr int lds = NW * 16 * 64 * 16;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
     }
     const unsigned grid = (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64));
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW>), dim3(grid), dim3(NW * 64), lds, stream, p);

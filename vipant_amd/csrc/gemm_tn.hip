@@ -526,15 +526,14 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     if (!direct || a_colsum != nullptr)
         VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= need, VIPANT_ENOWORKSPACE,
                        "gemm_tn: workspace too small (%zu < %zu)", workspace_bytes, need);
-    static bool configured = false;
+    static DeviceOnce once;
     static int variant = 0;
-    if (!configured) {
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * STAGE_BYTES));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            PP_LDS_BYTES));
         variant = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;     // bit 16: the two-stage kernel
-        configured = true;
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
@@ -592,10 +591,9 @@ extern "C" int32_t vipant_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, f
                    "gemm_tn_pair: per-split byte range exceeds 4 GiB");
     VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_gemm_tn_pair_workspace_bytes(M, P, Q), VIPANT_ENOWORKSPACE,
                    "gemm_tn_pair: workspace too small");
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-        configured = true;
     }
     hipStream_t s = (hipStream_t)stream;
     const int direct = splits == 1 ? 1 : 0;

@@ -331,11 +331,10 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     VIPANT_REQUIRE((uintptr_t)workspace % 256 == 0, VIPANT_EALIGN, "infonce: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const NceWs w = carve((char*)workspace, B, E);
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        configured = true;
     }
     const int K = (int)(3 * E);
     const unsigned tiles = (unsigned)(ceil_div(B, BM) * ceil_div(B, BN));

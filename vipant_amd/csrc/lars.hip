@@ -30,7 +30,18 @@ __global__ __launch_bounds__(256) void lars_norm_kernel(LarsArgs a) {
         chunk_range(a.n[t], c, &b, &e);
         const float* p = a.p[t];
         const float* g = a.g[t];
-        for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+        int64_t i0 = b;
+        if ((((uintptr_t)p | (uintptr_t)g) & 15) == 0) {      // chunk starts are multiples of 4 elements: 16-byte loads
+            const int64_t e4 = b + ((e - b) & ~(int64_t)3);
+            for (int64_t i = b + 4 * (int64_t)threadIdx.x; i < e4; i += 1024) {
+                const f32x4 pv = *(const f32x4*)(p + i);
+                const f32x4 dv = *(const f32x4*)(g + i) + a.wd * pv;
+                sp += (pv[0] * pv[0] + pv[1] * pv[1]) + (pv[2] * pv[2] + pv[3] * pv[3]);
+                sd += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+            }
+            i0 = e4;
+        }
+        for (int64_t i = i0 + threadIdx.x; i < e; i += 256) {
             const float pv = p[i], dv = g[i] + a.wd * pv;
             sp += pv * pv;
             sd += dv * dv;
@@ -68,7 +79,9 @@ __global__ __launch_bounds__(256) void lars_update_kernel(LarsArgs a) {
     const float* g = a.g[t];
     float* mu = a.mu[t];
     const float lr = a.lr[t], wd = adapt ? a.wd : 0.f;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+    // (16-byte accesses, as in the norm pass, make THIS pass slower: 305 -> 342 us over the 85 M parameters; four-byte ones stay)
+    const int64_t i0 = b;
+    for (int64_t i = i0 + threadIdx.x; i < e; i += 256) {
         const float pv = p[i];
         const float dp = (g[i] + wd * pv) * q;
         const float m = mu[i] * a.momentum + dp;

@@ -409,10 +409,9 @@ template <int EPL, int HPW, int MINB>
 int32_t launch_fwd(const bf16_t* qk, const bf16_t* h1, const int64_t* idx, bf16_t* ctx, float* probs, int batch, int S, int causal,
                    hipStream_t st) {
     const int lds = EPL * 4096 + 4096 + 1024 + 64 + 4 * HPW * ((S + 31) & ~31) * (int)sizeof(float);
-    static int configured = 0;
-    if (lds > configured) {
+    static DeviceMax most;
+    if (raise_on_device(most, lds)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_fwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = lds;
     }
     hipLaunchKernelGGL((rows_ctx_fwd_kernel<EPL, HPW, MINB>), dim3((unsigned)batch), dim3(256), lds, st, qk, h1, idx, ctx, probs, S, causal);
     VIPANT_LAUNCH_CHECK();
@@ -423,10 +422,9 @@ template <int EPL, int HPW, int MINB>
 int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, const bf16_t* h1, const int64_t* idx, const float* probs,
                    bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, hipStream_t st) {
     constexpr int lds = EPL * 4096 + 4096 + 1024 + 2048;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_bwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
     }
     hipLaunchKernelGGL((rows_ctx_bwd_kernel<EPL, HPW, MINB>), dim3((unsigned)batch), dim3(256), lds, st, qk, dctx, ctx, h1, idx, probs, dh1,
                        dqk, S, causal);

@@ -159,11 +159,10 @@ extern "C" int32_t vipant_retrieval_ranks(const float* x1, const float* x2, cons
     VIPANT_REQUIRE((uintptr_t)workspace % 256 == 0, VIPANT_EALIGN, "retrieval: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const RetWs w = carve((char*)workspace, N1, N2, E, G);
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce once;
+    if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)ret_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)ret_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        configured = true;
     }
     auto blocks = [](int64_t n) { const int64_t b = ceil_div(n, 256); return (unsigned)(b > 4096 ? 4096 : b); };
     hipLaunchKernelGGL(ret_prep_kernel, dim3(blocks(N1 * E)), dim3(256), 0, s, x1, w.x1cat, N1 * E, (int)E, 0);
