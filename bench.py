@@ -35,7 +35,7 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=Fa
     side, csrc/readout_ctx.hip): one row's 24 D^2 (the two folded projections are D x D per item) + scores and contexts against
     the LayerNorm output, 4 S H D with H = D / 64.  The zeros of the block-sparse head expansion are not counted."""
     full = S * (24 * width * width + 4 * S * width)
-    folded = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0" and width in (512, 768, 1024) and S <= 2048
+    folded = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0" and width in (512, 768, 1024) and S <= 1024
     if not (last_block_rows and layers > 0):
         last = full
     elif folded:

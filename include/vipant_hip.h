@@ -151,7 +151,8 @@ int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const i
  * W_v,h (sum_j p_j h1_j) + b_v,h, so the kernels run against the LayerNorm output h1 bf16 [batch*S, D] itself and the key / value
  * projection of every token (nn.MultiheadAttention's in_proj, clip/model.py:170-187 via cvap/module/val.py:519-522) is never formed.
  * qk bf16 [batch*H, D]: row (i, h) = W_k,h^T q_(i,h);  ctx bf16 [batch*H, D]: row (i, h) = sum_j p_j h1[i, j, :];
- * probs fp32 [batch, H, S] as above.  H = 8, 12 or 16 heads of 64 (D = 64 H); S <= 2048. */
+ * probs fp32 [batch, H, S] as above.  H = 8, 12 or 16 heads of 64 (D = 64 H); S <= 1024 (an item's raw scores wait
+ * in LDS beside the staged rows: 64 KiB at H = 16). */
 int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_t* idx, uint16_t* ctx, float* probs, int64_t batch,
                             int64_t S, int64_t H, int32_t causal, void* stream);
 /* dctx bf16 [batch*H, D]: row (i, h) = W_v,h^T dout_(i,h).  dh1 bf16 [batch*S, D]: the attention's gradient for EVERY token's h1 row

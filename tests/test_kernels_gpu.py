@@ -466,7 +466,8 @@ def test_mha_rows(ops, batch, S, H, causal, with_idx):
 
 
 @pytest.mark.parametrize("batch,S,H,causal,with_idx", [(3, 316, 12, False, False), (4, 77, 8, True, True), (2, 50, 12, False, True),
-                                                       (3, 257, 16, False, False), (2, 5, 8, True, True), (2, 645, 12, False, False)])
+                                                       (3, 257, 16, False, False), (2, 5, 8, True, True), (2, 645, 12, False, False),
+                                                       (1, 1024, 16, False, False)])     # the longest item the kernels take (LDS)
 def test_rows_ctx(ops, batch, S, H, causal, with_idx):
     """The one-query attention of the last block with the K / V projection folded into the query side (csrc/readout_ctx.hip) against
     its definition in fp64 autograd: contexts, softmax rows, dh1 of every token, dqk."""
@@ -500,6 +501,9 @@ def test_rows_ctx(ops, batch, S, H, causal, with_idx):
              dqk.data_ptr(), batch, S, H, int(causal), st)
     assert_close(dh1.view(batch, S, D), hd.grad, 2e-2, 2e-2 * hd.grad.abs().max().item(), "rows_ctx dh1")
     assert_close(dqk.view(batch, H, D), qd.grad, 2e-2, 2e-2 * qd.grad.abs().max().item(), "rows_ctx dqk")
+    if S == 1024:
+        with pytest.raises(Exception):      # one token more: refused (the caller takes the K / V form)
+            ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S + 1, H, int(causal), st)
     if causal:          # rows behind the limit get exact zeros, not the fill
         lim = idx if idx is not None else torch.zeros(batch, dtype=torch.long, device=DEV)
         behind = torch.arange(S, device=DEV).view(1, S) > lim.view(batch, 1)

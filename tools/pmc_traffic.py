@@ -30,6 +30,10 @@ KERNELS = {      # substring of the rocprofv3 kernel name -> (label, algorithmic
     # q, k, v, dO, O in; dq, dk, dv out (+ lse in, delta out and back in)
     "mha_bwd1_kernel<20>": ("mha_bwd1_kernel<20> b=512 S=316 H=12", QKV + 2 * 2 * M * D + QKV + 3 * 4 * 512 * 12 * 316),
     # the last block's one-query attention: K, V of every token in (+ probs out / in); backward: K (twice), V in, dK, dV out
+    # round 4: the same attention against the LayerNorm output h1 itself: h1 in (+ probs out); backward: h1 in, dh1 out (+ probs in)
+    "rows_ctx_fwd_kernel": ("rows_ctx_fwd_kernel b=512 S=316 H=12", 2 * M * D + 4 * 512 * 12 * 316),
+    "rows_ctx_bwd_kernel": ("rows_ctx_bwd_kernel b=512 S=316 H=12", 2 * 2 * M * D + 4 * 512 * 12 * 316),
+    "mha_bwd1s_kernel<20>": ("mha_bwd1s_kernel<20> b=512 S=316 H=12", QKV + 2 * 2 * M * D + QKV + 3 * 4 * 512 * 12 * 316),
     "mha_rows_fwd_kernel": ("mha_rows_fwd_kernel b=512 S=316 H=12", 2 * 2 * M * D + 4 * 512 * 12 * 316),
     "mha_rows_bwd_kernel": ("mha_rows_bwd_kernel b=512 S=316 H=12", 4 * 2 * M * D + 4 * 512 * 12 * 316),
 }

@@ -399,8 +399,8 @@ __global__ __launch_bounds__(256) void head_extract_kernel(const T* __restrict__
 }
 
 int32_t check_ctx(int64_t batch, int64_t S, int64_t H) {
-    VIPANT_REQUIRE(batch > 0 && S > 0 && S <= 2048 && (H == 8 || H == 12 || H == 16), VIPANT_EBADSHAPE,
-                   "rows_ctx: batch=%ld S=%ld H=%ld (heads of 64: H = 8, 12 or 16, i.e. width 512, 768 or 1024; S <= 2048)", (long)batch,
+    VIPANT_REQUIRE(batch > 0 && S > 0 && S <= 1024 && (H == 8 || H == 12 || H == 16), VIPANT_EBADSHAPE,
+                   "rows_ctx: batch=%ld S=%ld H=%ld (heads of 64: H = 8, 12 or 16, i.e. width 512, 768 or 1024; S <= 1024: the raw scores of an item wait in LDS)", (long)batch,
                    (long)S, (long)H);
     return VIPANT_OK;
 }

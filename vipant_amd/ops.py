@@ -531,7 +531,7 @@ class BackboneFn(torch.autograd.Function):
         if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
-        ctx_alg = prune and LAST_BLOCK_CTX and H in (8, 12, 16) and S <= 2048
+        ctx_alg = prune and LAST_BLOCK_CTX and H in (8, 12, 16) and S <= 1024
         # e4m3 operands in the NT contractions (configs[4]): a property of the tower, whether or not this call records a backward --
         # the no-grad feature pass of `running.micro_batch` and evaluation must see the forward the training pass differentiates
         fp8 = bool(fp8)
