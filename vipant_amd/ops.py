@@ -563,10 +563,11 @@ class BackboneFn(torch.autograd.Function):
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
                 mean1 = mean2 = mean; rstd1 = rstd2 = rstd
             if prune and l == L - 1:
-                # the last block on the read-out rows: bf16 contractions whatever `fp8` says.  All but one are `batch`-row launches; the
-                # exception is the K / V projection over every token (N = 2 D): it stays bf16 too, a documented departure from
-                # `running.fp8_gemm` for this one launch per tower (1 of 97 contraction launches; `running.last_block_rows=False`
-                # restores the e4m3 last block; both corners are under test_end_to_end_golden_e4m3)
+                # the last block on the read-out rows: bf16 contractions whatever `fp8` says -- all of them launches on `batch` or
+                # `batch * H` rows.  (Only the round-3 form, VIPANT_LAST_BLOCK_CTX=0, still has a per-token launch here, the K / V
+                # projection, N = 2 D: it stays bf16 too, a documented departure from `running.fp8_gemm` for 1 of 97 contraction
+                # launches.)  `running.last_block_rows=False` restores the e4m3 last block; both corners are under
+                # test_end_to_end_golden_e4m3
                 def newr(cols, dtype=BF16):
                     return torch.empty((batch, cols), dtype=dtype, device=dev)
                 xs = new(D, SDT) if y_prev is not None else None
