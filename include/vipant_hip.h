@@ -160,6 +160,12 @@ int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_
 int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1, const int64_t* idx,
                             const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S, int64_t H, int32_t causal,
                             void* stream);
+/* H independent products in one launch, C_h[M, N] = A_h[M, K] . B_h[N, K]^T (+ bias_h), bf16 in and out, operand h starting
+ * h * stride elements behind operand 0: the per-head contractions of the folded form (a head's 64 columns of the `batch` read-out
+ * rows against that head's block of W_k / W_v, and back) without the block-sparse [batch * H, D] operand of vipant_head_expand. */
+int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, const uint16_t* B, int64_t ldb, int64_t stride_b,
+                             uint16_t* C, int64_t ldc, int64_t stride_c, const float* bias, int64_t stride_bias, int64_t M, int64_t N,
+                             int64_t K, int64_t H, void* stream);
 /* rows bf16 [n, 64 H] -> out bf16 [n*H, 64 H]: row (i, h) = row i with every column outside head h's 64 zeroed -- the operand that
  * makes "per-head slice times the head's weight block" one [n*H, D] x [D, D] contraction. */
 int32_t vipant_head_expand(const uint16_t* rows, uint16_t* out, int64_t n, int64_t H, void* stream);

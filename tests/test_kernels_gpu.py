@@ -510,6 +510,29 @@ def test_rows_ctx(ops, batch, S, H, causal, with_idx):
         assert float(dh1.view(batch, S, D)[behind].abs().max() if behind.any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("n,H", [(512, 12), (37, 8), (3, 16)])
+def test_gemm_nt_heads(ops, n, H):
+    """The per-head contractions of the folded last block in one launch each (vipant_gemm_nt_heads): a head's 64 columns of `n` rows
+    against that head's block of a weight matrix and back -- against the block-sparse formulation they replace (head_expand +
+    [n H, D] x [D, D] + head_extract) and against fp32 torch."""
+    D = 64 * H
+    rows = rnd(n, D, seed=1, dtype=torch.bfloat16)
+    w = rnd(3 * D, D, seed=2, dtype=torch.bfloat16, scale=D ** -0.5)            # an in_proj_weight: rows D .. 2D are W_k
+    wt = w.t().contiguous()                                                     # [D, 3D]
+    bias = rnd(D, seed=3)
+    wide = ops.heads_to_wide(rows, wt[:, D:2 * D], torch.full((n * H, D), 7.0, dtype=torch.bfloat16, device=DEV), H)
+    ref = torch.einsum("nhc,hcd->nhd", rows.float().view(n, H, 64), w[D:2 * D].float().view(H, 64, D)).reshape(n * H, D)
+    assert_close(wide, ref, 1e-2, 1e-2, "heads_to_wide")
+    old = ops.gemm_nt(ops.head_expand(rows, H), wt[:, D:2 * D], torch.empty((n * H, D), dtype=torch.bfloat16, device=DEV))
+    assert_close(wide, old, 2 ** -7, 1e-3, "heads_to_wide vs the block-sparse form")
+    back = ops.wide_to_heads(wide, w[2 * D:], H, bias=bias)
+    ref = torch.einsum("nhd,hcd->nhc", wide.float().view(n, H, D), w[2 * D:].float().view(H, 64, D)).reshape(n, D) + bias
+    assert_close(back, ref, 1e-2, 2e-2, "wide_to_heads")
+    old = ops.head_extract(ops.gemm_nt(wide, w[2 * D:], torch.empty((n * H, D), dtype=torch.bfloat16, device=DEV), bias=bias), H)
+    assert_close(back, old, 2 ** -7, 2e-3, "wide_to_heads vs the block-sparse form")
+    assert_close(ops.wide_to_heads(wide, w[2 * D:], H), ref - bias, 1e-2, 2e-2, "wide_to_heads, no bias")
+
+
 def test_head_expand_extract(ops):
     for n, H in ((5, 12), (3, 8), (2, 16)):
         D = 64 * H

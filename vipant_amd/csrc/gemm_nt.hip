@@ -27,6 +27,8 @@ struct GemmNT {
     // patch) of the product lands in row item * (tok_p + 1) + patch + 1 of C and gets pos[patch + 1, :] added -- the patch
     // embedding written straight into the token matrix, whose class-token rows a one-row-per-item kernel fills
     int tok_p; const float* pos;
+    // few-rows kernel only: blockIdx.y = h picks one of `nb` independent products; operand h starts h * stride elements further
+    int64_t stride_a, stride_b, stride_c, stride_bias;
 };
 
 template <int EPI>
@@ -913,12 +915,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
     const int ntn = (p.N + 63) / 64;
     const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
     const int m0 = tm * 64, n0 = tn * 64;
+    const int64_t z = blockIdx.y;                            // (vipant_gemm_nt_heads: one product per head)
     const bf16_t *ap[4], *bp[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + 16 * i + r, n = n0 + 16 * i + r;
-        ap[i] = p.A + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + 8 * g;
-        bp[i] = p.B + (int64_t)(n < p.N ? n : p.N - 1) * p.ldb + 8 * g;
+        ap[i] = p.A + z * p.stride_a + (int64_t)(m < p.M ? m : p.M - 1) * p.lda + 8 * g;
+        bp[i] = p.B + z * p.stride_b + (int64_t)(n < p.N ? n : p.N - 1) * p.ldb + 8 * g;
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -960,8 +963,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) v += part[(ww * 16 + mi * 4 + j) * 64 + lane];
         if (m >= p.M || n4 >= p.N) continue;
-        const int64_t o = (int64_t)m * p.ldc + n4;
-        if (EPI != VIPANT_EPI_DQUICKGELU_D8 && p.bias != nullptr) v += *(const f32x4*)(p.bias + n4);
+        const int64_t o = z * p.stride_c + (int64_t)m * p.ldc + n4;
+        if (EPI != VIPANT_EPI_DQUICKGELU_D8 && p.bias != nullptr) v += *(const f32x4*)(p.bias + z * p.stride_bias + n4);
         if (EPI == VIPANT_EPI_BF16) {
             *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(v);
         } else if (EPI == VIPANT_EPI_F32) {
@@ -992,14 +995,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
 }
 
 template <int EPI, int NW>
-int32_t launch_skinny_nw(const GemmNT& p, hipStream_t stream) {
+int32_t launch_skinny_nw(const GemmNT& p, hipStream_t stream, int nb = 1) {
     constexpr int lds = NW * 16 * 64 * 16;
     static DeviceOnce once;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     const unsigned grid = (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64));
-    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW>), dim3(grid), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW>), dim3(grid, (unsigned)nb), dim3(NW * 64), lds, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -1078,6 +1081,24 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
             vipant_set_error("gemm_nt: unknown epilogue %d", epilogue);
             return VIPANT_EBADSHAPE;
     }
+}
+
+// H independent small products in one launch of the few-rows kernel: the per-head contractions of the folded last block
+// (csrc/readout_ctx.hip) -- a head's 64 columns of the `batch` read-out rows against the head's block of a weight matrix -- without
+// materialising the block-sparse [batch * H, D] operand (vipant_head_expand) or computing its zeros.
+extern "C" int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, const uint16_t* B, int64_t ldb, int64_t stride_b,
+                                        uint16_t* C, int64_t ldc, int64_t stride_c, const float* bias, int64_t stride_bias, int64_t M,
+                                        int64_t N, int64_t K, int64_t H, void* stream) {
+    VIPANT_REQUIRE(M > 0 && N > 0 && K > 0 && H > 0 && H < 65536 && K % 64 == 0 && N % 4 == 0, VIPANT_EBADSHAPE,
+                   "gemm_nt_heads: bad shape M=%ld N=%ld K=%ld H=%ld (K %% 64, N %% 4)", (long)M, (long)N, (long)K, (long)H);
+    VIPANT_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && stride_a % 8 == 0 &&
+                   stride_b % 8 == 0 && stride_c % 4 == 0 && stride_bias % 4 == 0, VIPANT_EALIGN,
+                   "gemm_nt_heads: leading dimensions / head strides must keep 16-byte (operands), 8-byte (C) and 16-byte (bias) alignment");
+    VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0) && ((uintptr_t)bias % 16 == 0),
+                   VIPANT_EALIGN, "gemm_nt_heads: operands must be 16-byte aligned");
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, nullptr, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, nullptr, nullptr, 0, nullptr,
+             stride_a, stride_b, stride_c, stride_bias};
+    return launch_skinny_nw<VIPANT_EPI_BF16, 4>(p, (hipStream_t)stream, (int)H);
 }
 
 // The patch embedding written straight into the token matrix: tokens[item * (P + 1) + patch + 1, :] = A[item * P + patch, :] . B^T +
