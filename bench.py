@@ -421,6 +421,19 @@ def main():
         out["infonce_alone"] = {"B": Bn, "E": E, "ms": round(nce_ms, 4), "tflops": round(6.0 * Bn * Bn * E / (nce_ms * 1e-3) / 1e12, 1),
                                 "note": "loss + dx1 + dx2 + dlogit_scale; the B x B fp32 logits are never stored, the bf16 s.dZ matrix and its transpose "
                                         "(2 x 32 MiB at B = 4096) are, between pass 2 and the gradient contraction"}
+        # the same group at the step's own batch on one GPU (row-block kernels up to 768 clips: csrc/infonce.hip)
+        Bs = 512
+        y1 = torch.nn.functional.normalize(torch.randn(Bs, E, device=dev), dim=-1).requires_grad_()
+        y2 = torch.nn.functional.normalize(torch.randn(Bs, E, device=dev), dim=-1).requires_grad_()
+        for _ in range(3):
+            ops.InfoNCEFn.apply(y1, y2, ls, None, 0, Bs, 1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.InfoNCEFn.apply(y1, y2, ls, None, 0, Bs, 1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        out["infonce_alone"]["ms_at_B512"] = round(e0.elapsed_time(e1) / 20, 4)
         if world == 1 and lbr and not args.no_full_last_block_check:
             # transparency: the same build, same box, with the towers' last block evaluated on EVERY token (what the reference
             # computes before its read-out discards all rows but one) -- a short untimed-region extra, never `value`

@@ -242,7 +242,9 @@ int32_t vipant_scatter_rows(const float* g, const int64_t* idx, float* dx, int64
  * scale_max <= 0 means +inf).  loss = mean_i CE(s x1 x2^T, i) + mean_i CE(s x2 x1^T, i).
  * Gradients are produced for rows [row0, row0+nrows) only (the rank's slice of an all-gathered batch):
  * dx1, dx2 fp32 [nrows, E], scaled by grad_scale; dlogit_scale is the full-batch value * grad_scale.
- * Any of dx1 / dx2 / dlogit_scale may be NULL (forward only).  E % 64 == 0. */
+ * Any of dx1 / dx2 / dlogit_scale may be NULL (forward only).  E % 64 == 0.  Up to 768 clips at E = 512 the call is three
+ * launches of row-block kernels (no B x B operand in HBM but the fp32 logits themselves, 2 B^2 floats); above, 256 x 256 tile
+ * kernels whose s.dZ makes a bf16 round trip.  Same results within the rounding of the bf16 gradient operands. */
 size_t vipant_infonce_workspace_bytes(int64_t B, int64_t E);
 int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, const float* logit_scale, float scale_max,
                                float* loss, float* dx1, float* dx2, float* dlogit_scale, float grad_scale,

@@ -589,9 +589,18 @@ def nce_inputs(B):
     return a, t
 
 
+@pytest.fixture(params=["rows", "tiles"])
+def nce_path(request, monkeypatch):
+    """Up to 768 clips the loss takes the row-block kernels (round 4), above that the 256 x 256 tile kernels; VIPANT_NCE_ROWS=0
+    (read per call) sends every batch through the tile kernels, so the small fixtures keep covering both."""
+    if request.param == "tiles":
+        monkeypatch.setenv("VIPANT_NCE_ROWS", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("B", [8, 32, 129])
 @pytest.mark.parametrize("tag", ["", "_clamp", "_hot"])
-def test_infonce_golden(ops, golden, B, tag):
+def test_infonce_golden(ops, golden, nce_path, B, tag):
     """K8 boundary against vectors produced by the reference's CELossHead: loss within 1e-3 (north-star
     tolerance; observed ~1e-5), gradients within 1 % of their scale (bf16 MFMA operands in the backward)."""
     g = golden(f"infonce_B{B}{tag}")
@@ -611,10 +620,10 @@ def test_infonce_golden(ops, golden, B, tag):
     assert abs(float(ls.grad) - float(g["dls"])) < 1e-4 + 1e-3 * abs(float(g["dls"])), (float(ls.grad), float(g["dls"]))
 
 
-@pytest.mark.parametrize("B,row0,nrows", [(512, 0, 512), (1000, 0, 1000), (1024, 256, 256), (4096, 3584, 512),
+@pytest.mark.parametrize("B,row0,nrows", [(512, 0, 512), (768, 512, 256), (769, 0, 769), (1000, 0, 1000), (1024, 256, 256), (4096, 3584, 512),
                                           (8192, 7168, 1024),                      # BASELINE.json configs[4]: 8 x 1024 clips
                                           (432, 108, 108), (432, 324, 108), (8, 4, 4), (30, 3, 5)])      # strips off the 8-row grid
-def test_infonce_large_and_sliced(ops, B, row0, nrows):
+def test_infonce_large_and_sliced(ops, nce_path, B, row0, nrows):
     from oracle import ref_cpu as R
     a = rnd(B, 512, seed=1); a = a / a.norm(dim=-1, keepdim=True)
     t = rnd(B, 512, seed=2); t = t / t.norm(dim=-1, keepdim=True)
@@ -740,7 +749,7 @@ def test_zero_shot_report_golden(golden):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 7, 9, 255, 257])
-def test_infonce_tiny_and_ragged_batches(ops, B):
+def test_infonce_tiny_and_ragged_batches(ops, nce_path, B):
     """Degenerate and ragged batch sizes (B = 1 gives loss 0 and zero gradients, as the reference's cross entropy does)."""
     from oracle import ref_cpu as R
     g = torch.Generator().manual_seed(B)

@@ -242,9 +242,11 @@ def test_two_replicas_local_negatives_match_oracle_mean_objective(tmp_path, monk
     # `running.last_block_rows` (this seed: 0.044 / 0.066, the noisiest of the six in both modes); the noisiest tensor
     # (near-cancelling LayerNorm-weight / bias gradients) 0.08 ... 0.23
     print("update-direction error vs the fp32 oracle: median %.4f max %.4f" % (dirs[len(dirs) // 2], dirs[-1]))
-    # the full last block keeps the round-2 budget; the read-out-row path (exact up to rounding: dh + dq rows are rounded to bf16
-    # twice) has its own, 1.2x its worst observed seed
-    assert dirs[len(dirs) // 2] < (8e-2 if rows else 5e-2) and dirs[-1] < 0.3, (rows, dirs[len(dirs) // 2], dirs[-1])
+    # the read-out-row path (exact up to rounding: dh + dq rows are rounded to bf16 twice) has 1.2x its
+    # worst observed seed; the full last block 1.2x ITS worst: 0.0506 since the loss takes the row-block kernels at this batch
+    # (round 4) -- the two InfoNCE paths are equally accurate against fp64 (dx rel-L2 2.1e-3 both, tools/nce_accuracy.py), the
+    # statistic moves with any change of rounding pattern
+    assert dirs[len(dirs) // 2] < (8e-2 if rows else 6e-2) and dirs[-1] < 0.3, (rows, dirs[len(dirs) // 2], dirs[-1])
 
 
 @pytest.mark.timeout(900)

@@ -18,6 +18,7 @@
 // pass 1's logits; everywhere else one bf16 term (K = E) moves a logit by ~2e-3 * s / 14, below the bf16 rounding of dZ itself.
 // exp / log in fp32.
 #include "nt_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,7 +30,13 @@ struct NceWs {       // carved out of the caller's workspace; all offsets 256-B 
     void* tn_ws;
     size_t tn_bytes, total;
     int Bp, rparts, cparts;
+    // the row-block path (B <= ROWS_MAX_B): transposed bf16 copies of x1 / x2 [E][Bp32], the fp32 logits of both sides
+    // [2][B][Bp128], per key-chunk partial (max, sum, sum * z) [2][KC][B] x 3, loss / dlogit_scale accumulators + ticket
+    bf16_t *x1t, *x2t;
+    float *zws, *pmax, *psum, *pwz, *accum;
+    int Bp32, Bp128, KC;
 };
+constexpr int ROWS_MAX_B = 768, ROWS_E = 512;      // 54 us against 114 at B = 512; at B = 1024 the tile kernels win (117 against 135)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -57,6 +64,15 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     const size_t pair_bytes = vipant_gemm_tn_pair_workspace_bytes(B, B, E);
     if (pair_bytes > w.tn_bytes) w.tn_bytes = pair_bytes;
     w.tn_ws = take(w.tn_bytes);
+    w.Bp32 = (int)((B + 31) / 32 * 32); w.Bp128 = (int)((B + 127) / 128 * 128); w.KC = w.Bp128 / 128;
+    const bool rows = B <= ROWS_MAX_B && E == ROWS_E;
+    w.x1t = (bf16_t*)take(rows ? (size_t)E * w.Bp32 * 2 : 0);
+    w.x2t = (bf16_t*)take(rows ? (size_t)E * w.Bp32 * 2 : 0);
+    w.zws = (float*)take(rows ? (size_t)2 * B * w.Bp128 * 4 : 0);
+    w.pmax = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
+    w.psum = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
+    w.pwz = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
+    w.accum = (float*)take(256);
     w.total = off;
     return w;
 }
@@ -64,12 +80,22 @@ NceWs carve(char* base, int64_t B, int64_t E) {
 // x -> [hi | hi | lo] (x1) or [hi | lo | hi] (x2).
 __global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                        const float* __restrict__ logit_scale, float scale_max, NceWs w,
-                                                       int B, int E) {
+                                                       int B, int E, int transposed) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float raw = __expf(logit_scale[0]);
         const bool clamped = scale_max > 0.f && raw > scale_max;
         w.scal[0] = clamped ? scale_max : raw;
         w.scal[1] = clamped ? 1.f : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) w.accum[threadIdx.x] = 0.f;       // (row-block path) sums and the ticket
+    if (transposed) {       // bf16(x)^T, [E][Bp32], columns B .. Bp32 zero: the gradient products read keys along rows
+        const int64_t tt = (int64_t)E * w.Bp32;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt; i += (int64_t)gridDim.x * 256) {
+            const int n = (int)(i % w.Bp32);
+            const int64_t e = i / w.Bp32;
+            w.x1t[i] = n < B ? (bf16_t)x1[(int64_t)n * E + e] : (bf16_t)0.f;
+            w.x2t[i] = n < B ? (bf16_t)x2[(int64_t)n * E + e] : (bf16_t)0.f;
+        }
     }
     const int64_t total = (int64_t)B * E;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -315,6 +341,199 @@ __global__ __launch_bounds__(256) void nce_final_kernel(NceWs w, int B, int npar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-block path for few clips (B <= 768: the step's own batch on one GPU).  Two launches behind the prep:
+//   lse    workgroup (key chunk of 128, block of 16 queries, side): the fp32-grade logits of 16 rows of Z (side 0: queries x1, keys
+//          x2) or of Z^T (side 1) against 128 keys -- [hi|hi|lo] . [hi|lo|hi] over K = 3 E as in the tile kernels, fragments straight
+//          from global memory (both operands K-contiguous), a wave per 32 keys -- left in HBM (2 B^2 floats: 2 MiB at B = 512) with
+//          the chunk's (max, sum exp, sum exp * z) per query;
+//   grad   workgroup (block of 16 queries, side): merges the chunks' triples into the two log-sum-exp vectors it needs (the first
+//          workgroup of each side also sums the loss and d logit_scale terms; the second to arrive writes them out), forms
+//          s dZ = s (softmax_row + softmax_col - 2 I) / B for its 16 rows in registers, 32 keys at a time, as the B operand of
+//          dx^T[columns x 16 rows] += x_other^T[columns x keys] . dZ^T -- the other operand from the transposed bf16 copy the prep
+//          leaves, so it is K-contiguous too: no LDS staging, no B x B matrix of dZ anywhere.
+template <int KS>
+__global__ __launch_bounds__(256) void nce_rows_lse_kernel(NceWs w, int B) {
+    __shared__ float red[4][3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int kc = blockIdx.x, blk = blockIdx.y, side = blockIdx.z;
+    const int K = KS * 32;
+    const bf16_t* Q = side == 0 ? w.x1cat : w.x2cat;
+    const bf16_t* Kx = side == 0 ? w.x2cat : w.x1cat;
+    const int m = 16 * blk + r;
+    const bf16_t* qp = Q + (int64_t)(m < B ? m : B - 1) * K + 8 * g;
+    const bf16_t* kp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 128 * kc + 32 * wave + 16 * t + r;
+        kp[t] = Kx + (int64_t)(n < B ? n : B - 1) * K + 8 * g;
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    constexpr int HALF = KS / 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        bf16x8 qf[HALF];
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) qf[s] = *(const bf16x8*)(qp + 32 * (half * HALF + s));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 kf[HALF];
+#pragma unroll
+            for (int s = 0; s < HALF; ++s) kf[s] = *(const bf16x8*)(kp[t] + 32 * (half * HALF + s));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < HALF; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[s], acc[t], 0, 0, 0);
+        }
+    }
+    // lane: query m = 16 blk + r, keys n0 + i of tile t, n0 = 128 kc + 32 wave + 16 t + 4 g
+    const float s = w.scal[0];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n0 = 128 * kc + 32 * wave + 16 * t + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + i;
+            const float z = (m < B && n < B) ? s * acc[t][i] : -INFINITY;
+            acc[t][i] = z;
+            mx = fmaxf(mx, z);
+            if (side == 0 && m == n && m < B) w.diag[m] = z;
+        }
+        if (m < B) *(f32x4*)(w.zws + ((int64_t)side * B + m) * w.Bp128 + n0) = acc[t];
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float ms = mx == -INFINITY ? 0.f : mx;
+    float se = 0.f, sw = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float z = acc[t][i];
+            const float e = __expf(z - ms);
+            se += e;
+            sw += z == -INFINITY ? 0.f : e * z;
+        }
+    se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+    sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
+    if (g == 0) { red[wave][0][r] = mx; red[wave][1][r] = se; red[wave][2][r] = sw; }
+    __syncthreads();
+    if (threadIdx.x < 16 && m < B) {        // the four waves' triples of query r, in a fixed order
+        float fm = -INFINITY;
+        for (int q = 0; q < 4; ++q) fm = fmaxf(fm, red[q][0][r]);
+        float fe = 0.f, fw = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const float pm = red[q][0][r];
+            if (pm == -INFINITY) continue;
+            const float f = __expf(pm - fm);
+            fe += red[q][1][r] * f;
+            fw += red[q][2][r] * f;
+        }
+        const int64_t o = ((int64_t)side * w.KC + kc) * B + m;
+        w.pmax[o] = fm; w.psum[o] = fe; w.pwz[o] = fw;
+    }
+}
+
+// the chunks' triples of index i on side sd -> (log-sum-exp, sum exp * z / sum exp); fixed order
+__device__ __forceinline__ void nce_rows_merge(const NceWs& w, int B, int sd, int i, float* lse, float* ez) {
+    float fm = -INFINITY;
+    for (int c = 0; c < w.KC; ++c) fm = fmaxf(fm, w.pmax[((int64_t)sd * w.KC + c) * B + i]);
+    float fe = 0.f, fw = 0.f;
+    for (int c = 0; c < w.KC; ++c) {
+        const int64_t o = ((int64_t)sd * w.KC + c) * B + i;
+        const float pm = w.pmax[o];
+        if (pm == -INFINITY) continue;
+        const float f = __expf(pm - fm);
+        fe += w.psum[o] * f;
+        fw += w.pwz[o] * f;
+    }
+    *lse = fm + __logf(fe);
+    *ez = fw / fe;
+}
+
+template <int E, int CPW>          // CPW: 16-column tiles per wave; blockIdx.z picks the workgroup's 64 CPW columns
+__global__ __launch_bounds__(256) void nce_rows_grad_kernel(NceWs w, int B, float* __restrict__ dx1, float* __restrict__ dx2, int row0,
+                                                            int nrows, float gscale, float* __restrict__ loss, float* __restrict__ dls) {
+    __shared__ float lse_o[ROWS_MAX_B];         // log-sum-exp of the OTHER side, per key
+    __shared__ float lse_q[16];
+    __shared__ float red[2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int blk = blockIdx.x, side = blockIdx.y, col0 = blockIdx.z * (64 * CPW) + 16 * CPW * wave;
+    float* dx = side == 0 ? dx1 : dx2;
+    const bool in_strip = dx != nullptr && 16 * blk < row0 + nrows && 16 * blk + 16 > row0;
+    const bool sums = blk == 0 && blockIdx.z == 0;
+    if (!sums && !in_strip) return;
+    float lsum = 0.f, esum = 0.f;
+    for (int n = threadIdx.x; n < B; n += 256) {
+        float l, e;
+        nce_rows_merge(w, B, side ^ 1, n, &l, &e);
+        lse_o[n] = l;
+        const float d = w.diag[n];
+        lsum += l - d;
+        esum += e - d;
+    }
+    if (threadIdx.x < 16 && 16 * blk + (int)threadIdx.x < B) {
+        float l, e;
+        nce_rows_merge(w, B, side, 16 * blk + threadIdx.x, &l, &e);
+        lse_q[threadIdx.x] = l;
+    }
+    if (sums) {         // this side's first workgroup owns the other side's share of the loss and of d logit_scale
+        red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = esum;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd(w.accum + 0, red[0][0]);          // two terms in all: a + b = b + a, the order of arrival does not show
+            atomicAdd(w.accum + 1, red[1][0]);
+            __threadfence();
+            if (atomicAdd((unsigned int*)(w.accum + 2), 1u) == 1u) {      // the second of the two
+                __threadfence();
+                const float a = atomicAdd(w.accum + 0, 0.f), b = atomicAdd(w.accum + 1, 0.f);
+                loss[0] = a / (float)B;
+                if (dls != nullptr) dls[0] = w.scal[1] != 0.f ? 0.f : b * gscale / (float)B;
+            }
+        }
+    }
+    __syncthreads();
+    if (!in_strip) return;
+    // lane (r, g): query m = 16 blk + r as the B-operand column, keys k0 + 8 g .. + 7 as its K slots
+    const int m = 16 * blk + r;
+    const float lq = lse_q[r < 16 ? r : 0];
+    const float s = w.scal[0], kf = gscale / (float)B * s;
+    const float* zrow = w.zws + ((int64_t)side * B + (m < B ? m : B - 1)) * w.Bp128 + 8 * g;
+    const bf16_t* xt = (side == 0 ? w.x2t : w.x1t) + (int64_t)(col0 + r) * w.Bp32 + 8 * g;       // rows = this wave's columns
+    f32x4 acc[CPW];
+#pragma unroll
+    for (int ct = 0; ct < CPW; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = w.Bp32 / 32;
+#pragma unroll 4
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const int k0 = 32 * ks;
+        bf16x8 xf[CPW];
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) xf[ct] = *(const bf16x8*)(xt + (int64_t)16 * ct * w.Bp32 + k0);
+        const f32x4 z0 = *(const f32x4*)(zrow + k0), z1 = *(const f32x4*)(zrow + k0 + 4);
+        bf16x8 bd;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = k0 + 8 * g + e;
+            const float z = e < 4 ? z0[e] : z1[e - 4];
+            float d = 0.f;
+            if (m < B && n < B) d = (__expf(z - lq) + __expf(z - lse_o[n]) - (m == n ? 2.f : 0.f)) * kf;
+            bd[e] = (bf16_t)d;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ct], bd, acc[ct], 0, 0, 0);
+    }
+    if (m >= row0 && m < row0 + nrows && m < B) {
+        float* orow = dx + (int64_t)(m - row0) * E + col0 + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) *(f32x4*)(orow + 16 * ct) = acc[ct];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t vipant_infonce_workspace_bytes(int64_t B, int64_t E) { return carve(nullptr, B, E).total; }
@@ -339,9 +558,23 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     const int K = (int)(3 * E);
     const unsigned tiles = (unsigned)(ceil_div(B, BM) * ceil_div(B, BN));
     int64_t pb = ceil_div(B * E, 256);
+    const char* rows_env = getenv("VIPANT_NCE_ROWS");
+    const bool rows_path = B <= ROWS_MAX_B && E == ROWS_E && !(rows_env && rows_env[0] == '0');
     hipLaunchKernelGGL(nce_prep_kernel, dim3((unsigned)(pb > 2048 ? 2048 : pb)), dim3(256), 0, s, x1, x2, logit_scale,
-                       scale_max, w, (int)B, (int)E);
+                       scale_max, w, (int)B, (int)E, rows_path ? 1 : 0);
     VIPANT_LAUNCH_CHECK();
+    if (rows_path) {
+        // few clips (the step's own batch on one GPU): 256 x 256 tiles would leave this on 4-16 CUs for three dependent
+        // launches of 40-50 us each; row blocks of 16 against key chunks of 128 fill the chip and need no B x B operand in HBM
+        const bool want = (dx1 != nullptr || dx2 != nullptr) && nrows > 0;
+        hipLaunchKernelGGL(nce_rows_lse_kernel<3 * ROWS_E / 32>, dim3((unsigned)w.KC, (unsigned)ceil_div(B, 16), 2), dim3(256), 0, s, w, (int)B);
+        VIPANT_LAUNCH_CHECK();
+        // two 16-column tiles per wave (128 columns per workgroup): 53.6 us per call at B = 512 against 55.4 / 60.2 with four / eight
+        hipLaunchKernelGGL((nce_rows_grad_kernel<ROWS_E, 2>), dim3((unsigned)ceil_div(B, 16), 2, ROWS_E / 128), dim3(256), 0, s, w, (int)B,
+                           want ? dx1 : nullptr, want ? dx2 : nullptr, (int)row0, (int)nrows, grad_scale, loss, dlogit_scale);
+        VIPANT_LAUNCH_CHECK();
+        return VIPANT_OK;
+    }
     hipLaunchKernelGGL(nce_tile_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES, s, w, (int)B, K, 0, (int)B, 1.0f);
     VIPANT_LAUNCH_CHECK();
     const int nparts = (int)ceil_div(B, 16);
