@@ -19,6 +19,8 @@ bi=[i for i,n in enumerate(names) if 'rows_ctx_bwd' in n and '12' in n]
 print(len(fi),len(bi))
 # audio forward is the one with the big grid neighbours: pick the occurrence whose duration is largest
 fa=max(fi[-4:], key=lambda i:int(rows[i]['End_Timestamp'])-int(rows[i]['Start_Timestamp']))
-show(fa-8,fa+14); print('----'); i=bi[-1]; show(i-22,i+18)
+i=bi[-1]
+fa=max(j for j in fi if j < i)
+show(fa-8,i+18)
 PY
 rm -f gpurun_out/r4f_trace.csv
