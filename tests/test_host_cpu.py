@@ -235,3 +235,27 @@ def test_fp8_switch_is_off_by_default_and_composes():
             "+model/loss=ce +optimizer=standard +running/audio=default").split()
     assert compose(base).running.get("fp8_gemm", None) is False
     assert compose(base + ["running.fp8_gemm=True"]).running.fp8_gemm is True
+
+
+def test_bench_flop_count_follows_the_last_block_form(monkeypatch):
+    """`bench.py` counts the work the step does: full last block > last block on its read-out rows with the K / V projection of
+    every token (round 3) > the folded form (round 4: no per-token projection; SURVEY.md 8-D4 for the full block)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    S, D, Lyr = 316, 768, 12
+    full = bench.tower_fwd_flops(S, 1024, S - 1, width=D, layers=Lyr)
+    assert full == Lyr * S * (24 * D * D + 4 * S * D) + 2 * (S - 1) * 1024 * D + 2 * D * 512
+    monkeypatch.setenv("VIPANT_LAST_BLOCK_CTX", "0")
+    kv = bench.tower_fwd_flops(S, 1024, S - 1, width=D, layers=Lyr, last_block_rows=True)
+    monkeypatch.delenv("VIPANT_LAST_BLOCK_CTX")
+    folded = bench.tower_fwd_flops(S, 1024, S - 1, width=D, layers=Lyr, last_block_rows=True)
+    assert full - kv == S * (24 * D * D + 4 * S * D) - (4 * S * D * D + 20 * D * D + 4 * S * D)
+    assert kv - folded == (4 * S * D * D + 20 * D * D + 4 * S * D) - (24 * D * D + 4 * S * (D // 64) * D)
+    assert 0.012 < (kv - folded) / kv < 0.015                     # 1.4 % of a 12-block tower at S = 316
+    # a width or a length the folded kernels do not take is counted in the round-3 form
+    assert bench.tower_fwd_flops(2000, 1024, 1999, width=D, layers=2, last_block_rows=True) == \
+        S * 0 + (2 - 1) * 2000 * (24 * D * D + 4 * 2000 * D) + (4 * 2000 * D * D + 20 * D * D + 4 * 2000 * D) + 2 * 1999 * 1024 * D + 2 * D * 512
