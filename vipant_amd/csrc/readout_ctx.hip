@@ -6,8 +6,9 @@
 //     scores_j   = q_h . (W_k,h h1_j + b_k,h) / 8 = (W_k,h^T q_h) . h1_j / 8 + const          (the constant cancels in the softmax)
 //     o_h        = sum_j p_j (W_v,h h1_j + b_v,h)  = W_v,h (sum_j p_j h1_j) + b_v,h            (sum_j p_j = 1)
 // i.e. per (item, head) a query-like vector qk_h = W_k,h^T q_h of width D and a context ctx_h = sum_j p_j h1_j of width D, both
-// against the LayerNorm output h1 itself.  The projections that remain are [batch * H, D] x [D, D] contractions (block-sparse head
-// expansion of the `batch` rows: `vipant_head_expand` / `vipant_head_extract`).  Backward: with dctx_h = W_v,h^T do_h,
+// against the LayerNorm output h1 itself.  The projections that remain are per-head products on the `batch` read-out rows
+// (`vipant_gemm_nt_heads`; the block-sparse [batch * H, D] operand of `vipant_head_expand` only feeds the two weight gradients).
+// Backward: with dctx_h = W_v,h^T do_h,
 //     dp_j = dctx_h . h1_j,  delta = dctx_h . ctx_h,  ds_j = p_j (dp_j - delta) / 8,
 //     dh1_j = sum_h p_j,h dctx_h + ds_j,h qk_h        (rank-2H update per token),     dqk_h = sum_j ds_j,h h1_j.
 // Both kernels stream h1 (fwd: read; bwd: read + write dh1) in place of the K / V projection, its dX, its dW and the two one-query
@@ -52,13 +53,6 @@ __device__ __forceinline__ void widen(const RawRow<EPL>& r, float (&x)[EPL]) {
 }
 template <int EPL>
 __device__ __forceinline__ void load_row(const bf16_t* row, int lane, float (&x)[EPL]) { widen<EPL>(load_raw<EPL>(row, lane), x); }
-template <int EPL>
-__device__ __forceinline__ void store_row(bf16_t* row, int lane, const float (&x)[EPL]) {
-#pragma unroll
-    for (int t = 0; t < EPL / 4; ++t)
-        *(bf16x4*)(row + 256 * t + 4 * lane) = f32x4_to_bf16x4(f32x4{x[4 * t], x[4 * t + 1], x[4 * t + 2], x[4 * t + 3]});
-}
-
 __device__ __forceinline__ int key_limit(const int64_t* idx, int item, int S, int causal) {
     if (!causal || idx == nullptr) return S;
     const int64_t v = idx[item];
