@@ -167,7 +167,9 @@ int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, c
                              uint16_t* C, int64_t ldc, int64_t stride_c, const float* bias, int64_t stride_bias, int64_t M, int64_t N,
                              int64_t K, int64_t H, void* stream);
 /* rows bf16 [n, 64 H] -> out bf16 [n*H, 64 H]: row (i, h) = row i with every column outside head h's 64 zeroed -- the operand that
- * makes "per-head slice times the head's weight block" one [n*H, D] x [D, D] contraction. */
+ * makes "per-head slice times the head's weight block" one dense contraction.  The step uses it for the two weight gradients of
+ * the folded form (dW_v = expand(do)^T ctx, dW_k = expand(q)^T dqk through vipant_gemm_tn); the activations' products go through
+ * vipant_gemm_nt_heads. */
 int32_t vipant_head_expand(const uint16_t* rows, uint16_t* out, int64_t n, int64_t H, void* stream);
 /* its inverse on a product: rows[i, 64 h + c] = full[(i, h), 64 h + c] (+ bias[64 h + c]); full bf16 or fp32 [n*H, 64 H]. */
 int32_t vipant_head_extract(const void* full, int32_t full_is_f32, const float* bias, uint16_t* rows, int64_t n, int64_t H,
