@@ -770,6 +770,49 @@ def test_infonce_tiny_and_ragged_batches(ops, nce_path, B):
 
 
 
+def test_round4_kernels_are_repeatable_under_load(ops):
+    """The same race screen for the kernels of round 4 that stage through LDS-DMA or split work between waves: the folded last-block
+    attention (forward, backward), the few-rows contraction (plain and per-head), the row-block InfoNCE -- sixty launches each at the
+    step's shapes with a bandwidth hog on a second stream; bit-identical results every time (the InfoNCE loss is two atomic adds onto
+    zero: a + b = b + a)."""
+    b, S, H = 96, 316, 12
+    D = 64 * H
+    st = torch.cuda.current_stream().cuda_stream
+    qk = rnd(b * H, D, seed=1, dtype=torch.bfloat16, scale=0.35); h1 = rnd(b * S, D, seed=2, dtype=torch.bfloat16)
+    dctx = rnd(b * H, D, seed=3, dtype=torch.bfloat16)
+    rows = rnd(512, D, seed=4, dtype=torch.bfloat16); w = rnd(3 * D, D, seed=5, dtype=torch.bfloat16, scale=D ** -0.5)
+    wt = w.t().contiguous(); bias = rnd(D, seed=6)
+    x1 = torch.nn.functional.normalize(rnd(512, 512, seed=7), dim=-1); x2 = torch.nn.functional.normalize(rnd(512, 512, seed=8) + 0.5 * x1, dim=-1)
+    hog_src = torch.empty(64 << 20, dtype=torch.float32, device=DEV); hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    ref = None
+    for it in range(60):
+        if it % 2:
+            with torch.cuda.stream(side):
+                hog_dst.copy_(hog_src)
+        ctx = torch.empty(b * H, D, dtype=torch.bfloat16, device=DEV); probs = torch.empty(b, H, S, device=DEV)
+        ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, ctx.data_ptr(), probs.data_ptr(), b, S, H, 0, st)
+        dh1 = torch.empty(b * S, D, dtype=torch.bfloat16, device=DEV); dqk = torch.empty(b * H, D, dtype=torch.bfloat16, device=DEV)
+        ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
+                 dqk.data_ptr(), b, S, H, 0, st)
+        few = ops.gemm_nt(rows, w[:D], torch.empty(512, D, dtype=torch.bfloat16, device=DEV), bias=bias, few_rows=True)
+        res = ops.gemm_nt(rows, w[:D], torch.empty(512, D, device=DEV), bias=bias, aux=x1[:, :1].expand(512, D).contiguous(),
+                          epi=ops.EPI_RESIDUAL_F32, few_rows=True)
+        wide = ops.heads_to_wide(rows, wt[:, D:2 * D], torch.empty(512 * H, D, dtype=torch.bfloat16, device=DEV), H)
+        back = ops.wide_to_heads(wide, w[2 * D:], H, bias=bias)
+        a_, t_ = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+        ls = torch.tensor(2.6593, device=DEV, requires_grad=True)
+        loss = ops.InfoNCEFn.apply(a_, t_, ls, None, 0, 512, 1.0)
+        loss.backward()
+        cur = (ctx, probs, dh1, dqk, few, res, wide, back, loss.detach().clone(), a_.grad, t_.grad, ls.grad)
+        if ref is None:
+            ref = cur
+        else:
+            for k, (r_, c_) in enumerate(zip(ref, cur)):
+                assert torch.equal(r_, c_), (it, k)
+    torch.cuda.synchronize()
+
+
 def test_pingpong_kernels_are_repeatable_under_load(ops):
     """Race screen for the ping-pong schedules: the same NT (bf16 and code epilogues) and TN launches forty times, interleaved with
     a bandwidth hog on a second stream that moves the LDS-DMA landing times around; every result must equal the first bit for bit
