@@ -841,3 +841,44 @@ def test_pingpong_kernels_are_repeatable_under_load(ops):
             for r_, c_ in zip(ref, cur):
                 assert torch.equal(r_, c_), it
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(40448, 3072, 768, "bf16"), (40448, 3072, 768, "gelu8"), (40448, 3072, 768, "dgelu8"),
+                                       (70000, 768, 3072, "bf16"), (50001, 2304, 768, "bf16")])
+def test_gemm_nt_ticket_walk_equals_static_walk(ops, monkeypatch, M, N, K, epi):
+    """Round 5: the persistent NT kernels draw their tiles from per-XCD ticket queues (common.h) so that a workgroup whose CU is held
+    by another stream's kernel -- the RCCL all-reduce of a gradient bucket -- costs 1/256 of a launch, not a round.  Which workgroup
+    computes a tile must not matter: bit-identical to the static-stride walk (VIPANT_GEMM_VARIANT bit 22), with the chip to itself
+    and with 64 CUs held for 300 us / 24 CUs for 3 ms by `vipant_comm_shadow` on a second stream (late workgroups, some finding their
+    queue empty); every element written each time (the ticket block must be back at zero after every launch)."""
+    a = rnd(M, K, seed=61, dtype=torch.bfloat16); b = rnd(N, K, seed=62, dtype=torch.bfloat16, scale=K ** -0.5)
+    bias = rnd(N, seed=63)
+    code_in = torch.randint(0, 256, (M, N), dtype=torch.uint8, device=DEV)
+    src = torch.empty(28 << 20, dtype=torch.uint8, device=DEV); dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+
+    def run():
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if epi == "bf16":
+            ops.gemm_nt(a, b, c, bias=bias, epi=ops.EPI_BF16)
+            return (c,)
+        if epi == "gelu8":
+            code = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+            ops.gemm_nt(a, b, c, bias=bias, aux=code, epi=ops.EPI_QUICKGELU_D8)
+            return (c, code)
+        ops.gemm_nt(a, b, c, aux=code_in, epi=ops.EPI_DQUICKGELU_D8)
+        return (c,)
+
+    monkeypatch.setenv("VIPANT_GEMM_VARIANT", "4194304")
+    ref = run()
+    assert all(torch.isfinite(t.float()).all() for t in ref)
+    monkeypatch.setenv("VIPANT_GEMM_VARIANT", "0")
+    for held, us in [(0, 0.0), (64, 300.0), (0, 0.0), (24, 3000.0), (0, 0.0)]:
+        if held:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.call("vipant_comm_shadow", src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
+        got = run()
+        for r_, g_ in zip(ref, got):
+            assert torch.equal(r_, g_), (held, us)
+    torch.cuda.synchronize()

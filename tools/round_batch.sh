@@ -1,0 +1,30 @@
+#!/bin/bash
+# One gpurun call = one batch: `gpurun --timeout S -- 'bash tools/round_batch.sh <batch> [tag]'`.  Everything a batch writes goes
+# to gpurun_out/<tag>_* (scratch; what is to be judged is copied into profiles/ afterwards).  Replaces the per-call r4_*.sh scripts.
+#   tests      the whole GPU suite
+#   bench      default bench.py line (20 steps) -> <tag>_bench.json
+#   shadow     tools/comm_shadow.py -> <tag>_comm_shadow.json
+#   prof       rocprofv3 kernel trace of 10 serial steps + per-shape table -> <tag>_kernel_stats_serial.csv, <tag>_kernel_shapes_serial.txt
+#   pmc        HBM traffic of the dominant kernels (separate --pmc passes) -> <tag>_pmc_traffic.json
+set -u
+batch=${1:-tests}; tag=${2:-r5}
+mkdir -p gpurun_out
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+case "$batch" in
+  tests)  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ;;
+  bench)  timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 3000 gpurun_out/${tag}_bench.json ;;
+  shadow) timeout 1500 python tools/comm_shadow.py --out gpurun_out/${tag}_comm_shadow.json 2>&1 | tail -60 ;;
+  prof)
+    rm -rf /tmp/prof && VIPANT_TOWER_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- \
+        python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-full-last-block-check > gpurun_out/${tag}_bench_prof.json 2> gpurun_out/${tag}_prof.err
+    f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/${tag}_kernel_stats_serial.csv
+    python tools/kstats_shapes.py /tmp/prof 10 > gpurun_out/${tag}_kernel_shapes_serial.txt
+    head -40 gpurun_out/${tag}_kernel_shapes_serial.txt ;;
+  pmc)
+    rm -rf /tmp/pmc_f /tmp/pmc_w
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-full-last-block-check > /dev/null 2> gpurun_out/${tag}_pmc.err
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-full-last-block-check > /dev/null 2>> gpurun_out/${tag}_pmc.err
+    python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w gpurun_out/${tag}_pmc_traffic.json | tail -40 ;;
+  *) echo "unknown batch $batch"; exit 2 ;;
+esac

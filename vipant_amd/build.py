@@ -28,7 +28,10 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # step, and the kernel is VALU-issue bound).  With the VGPR form forced, accumulators land where the arithmetic needs them and the
 # resident operand fragments take the AGPRs (pinned there by "+a" constraints in the source); the two-waves-per-SIMD kernels of the
 # file were VGPR-form already.
-EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"],
+# gemm_nt.hip, second option: the ticket walk draws a tile with ONE atomic add per workgroup whose result is needed a tile later; the
+# atomic optimizer rewrites a uniform atomic as "first active lane adds, s_waitcnt vmcnt(0), readfirstlane" -- a full wait (every
+# LDS-DMA piece in flight included) at the place where the draw is issued.
+EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"],
                 "attention_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]}
 
 

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -27,4 +31,27 @@ extern "C" int32_t vipant_device_check(void) {
         return VIPANT_EHIP;
     }
     return VIPANT_OK;
+}
+
+// The ticket block of a (device, stream) pair (common.h): allocated and zeroed on the pair's first persistent launch, kept for the
+// life of the process.  The kernels leave it zeroed, so nothing is done per launch.
+uint32_t* vipant_ticket_block(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, uint32_t*> blocks;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        vipant_set_error("ticket block: hipGetDevice failed");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = blocks.find({dev, stream});
+    if (it != blocks.end()) return it->second;
+    uint32_t* p = nullptr;
+    if (hipMalloc((void**)&p, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(p, 0, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        vipant_set_error("ticket block: allocation of %zu bytes failed", VIPANT_TICKET_WORDS * sizeof(uint32_t));
+        return nullptr;
+    }
+    blocks[{dev, stream}] = p;
+    return p;
 }

@@ -199,10 +199,15 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
            plan ? plan->dy_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
            VIPANT_EPI_DQUICKGELU_D8 | few, stream));
-    TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
+    // (Order, round 5: both input-gradient contractions first, then both weight gradients.  The NT kernels walk their tiles by
+    // tickets and lose 1/256 of a launch per CU another stream holds; a weight-gradient launch is one wave of <= 256 long
+    // workgroups and waits for a held CU.  The replica group's bucket all-reduce starts at a block boundary, i.e. right here: the
+    // first 1.5 ms of a block's backward are now the two launches that tolerate it.  du is also read while it is still in the
+    // 256 MB cache.)
     TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D,
            4 * D, VIPANT_EPI_BF16 | few, stream));
+    TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
     return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,

@@ -29,6 +29,9 @@ struct GemmNT {
     int tok_p; const float* pos;
     // few-rows kernel only: blockIdx.y = h picks one of `nb` independent products; operand h starts h * stride elements further
     int64_t stride_a, stride_b, stride_c, stride_bias;
+    // ping-pong kernel only: the stream's ticket block (common.h) -- tiles beyond a workgroup's first two are drawn from its XCD's
+    // queue instead of the static stride; NULL: static walk
+    uint32_t* tk = nullptr;
 };
 
 template <int EPI>
@@ -559,6 +562,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
     const int nk = p.K / (ES == 2 ? BK : 2 * BK);
+    // Ticket walk (common.h; the host sets p.tk only for a full grid whose every queue is longer than two rounds).  A workgroup's
+    // first two tiles are the static walk's (positions b >> 3 and 32 + (b >> 3) of queue b & 7: nothing to wait for at start-up); from
+    // the third on, positions come from the queue's counter.  The stream needs a tile's successor one tile ahead, the LDS is full
+    // and `vmcnt` retires in order (anything slow in front of the counted LDS-DMA waits stalls them), so a ticket travels without a
+    // wait of its own: wave 0 draws it at the START of an epilogue (the atomic has the whole epilogue to return), holds it until
+    // the next tile's bias round trip (the one full wait a tile has anyway: the value is there), writes it to the workgroup's
+    // mailbox (two words, alternating), and every wave reads that word in the bias round trip of the tile after that.  A workgroup
+    // therefore holds claims on three tiles beyond the one it computes.  (gemm_nt.hip is compiled with the atomic optimizer off:
+    // it turns a uniform atomic into "first lane adds, wait, broadcast" -- a full wait where the draw is issued.)
+    const bool dyn = p.tk != nullptr;
+    constexpr int NO_TILE = 0x3FFFFFFF;
+    const int xq = blockIdx.x & 7;
+    int qlen_own;
+    if (GROUPED) {
+        int rows = ntm - (xq & 3) * ppx;
+        rows = rows < 0 ? 0 : (rows > ppx ? ppx : rows);
+        qlen_own = rows * cg;
+    } else {
+        int rem = (ntiles & 255) - xq * 32;
+        rem = rem < 0 ? 0 : (rem > 32 ? 32 : rem);
+        qlen_own = (ntiles >> 8) * 32 + rem;
+    }
+    uint32_t* const mbox = dyn ? p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x : nullptr;
+    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 64 + value)
+    bool tk_dry = false;                        // thread 0: the queue is empty, stop drawing
+    int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
+    auto tk_tile = [&](uint32_t drawn) {
+        const int pos = 64 + (int)drawn;
+        if (pos < qlen_own) return tickets::tile_of(xq, pos);
+        tk_dry = true;
+        return NO_TILE;
+    };
+    if (dyn && tid == 0) tk_pend = tickets::take(p.tk + xq, 2u);      // tiles 2 and 3 of this workgroup
 
     // DMA: wave fills row blocks wave*4 .. wave*4+3 (8 rows x 128 B) of the tile's A and B rows, as in the kernel above
     uint32_t voffA[2], voffB[2];
@@ -718,8 +754,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #undef VIPANT_MX_ROW
     };
 
-    int tile = lane_pos;
-    TileDesc cur = describe(tile), nxt = describe(tile + G);
+    int tile = lane_pos, tile_nxt = lane_pos + G;
+    TileDesc cur = describe(tile), nxt = describe(tile_nxt);
     int gk = 0, slot = 0;                       // K-tile counter of the stream: A stage = gk & 1, B slot = gk % 3
     if (ES == 1) {
         load_scales(cur, sav, sbv);
@@ -747,10 +783,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     }
+    if (dyn && tid == 0) {       // (the draw returned with the prologue's loads)
+        tickets::put(mbox, (uint32_t)tk_tile(tk_pend));
+        tk_pend += 1u;
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the lag: group 1 runs one barrier interval behind group 0
 
     while (tile < ntiles) {
+        uint32_t tk_next = 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -765,9 +806,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
                 if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);    // not awaited here
                 if (ES == 1) load_scales(nxt, sav_n, sbv_n);                  // the next tile's scales ride the same round trip
+                if (dyn) tk_next = tickets::get(mbox + tk_par);               // and so does the ticket of the tile after the next
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
                 if (ES == 1) asm volatile("" : "+v"(sav_n[0]), "+v"(sav_n[1]), "+v"(sbv_n));
+                if (dyn) {
+                    asm volatile("" : "+v"(tk_next));
+                    // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
+                    if (tid == 0) tickets::put(mbox + (tk_par ^ 1), (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend)));
+                    tk_par ^= 1;
+                }
             }
             if (DEEP) {
                 // interval 0 (row tiles 0-3): B rows of K-tile k+2 (its slot was last read one interval ago by the lagging group),
@@ -828,24 +876,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
+        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(p.tk + xq);        // not awaited here
         pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
-        tile += G;
+        tile = tile_nxt;
+        tile_nxt = dyn ? __builtin_amdgcn_readfirstlane((int)tk_next) : tile_nxt + G;
         cur = nxt;
-        nxt = describe(tile + G);
+        nxt = describe(tile_nxt);
         if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; sbv = sbv_n; }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
+    if (dyn && tid == 0) tickets::finish(p.tk, gridDim.x);      // every draw of this workgroup has returned (tk_dry, or published)
 }
 
 template <int EPI, int VAR, int ES = 2>
-int32_t launch_pp_variant(const GemmNT& p, hipStream_t stream) {
+int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     static DeviceOnce once;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
     }
-    const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    GemmNT p = p_in;
+    const int64_t ntm = ceil_div(p.M, BM), ntn = ceil_div(p.N, BN);
+    const int64_t tiles = ntm * ntn;
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
+    // ticket walk (common.h) when every XCD's queue holds more than the two rounds a workgroup takes statically: the shortest queue
+    // of the plain walk is the last one, of the column-grouped walk (VAR 8) the one of the last row quarter
+    const int64_t ppx = (ntm + 3) / 4;
+    const int64_t shortest = VAR == 8 ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
+                                      : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
+    if (grid == 256 && shortest > 64 && !(p.dbg & 4194304)) {          // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
+        p.tk = vipant_ticket_block(stream);
+        if (p.tk == nullptr) return VIPANT_EHIP;
+    }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
@@ -1130,8 +1192,9 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
                    "gemm_nt_e4m3: operands must be 16-byte aligned");
     VIPANT_REQUIRE(sa != nullptr && sb != nullptr, VIPANT_EBADSHAPE, "gemm_nt_e4m3: the row scales of both operands are required");
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
-    static const int fp8_dbg = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;
-    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, sa, sb, 0, nullptr};
+    const char* var = getenv("VIPANT_GEMM_VARIANT");       // read per call, as in vipant_gemm_nt
+    const int fp8_dbg = var ? atoi(var) : 0;
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, fp8_dbg & 4194304, sa, sb, 0, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case VIPANT_EPI_BF16:

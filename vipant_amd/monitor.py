@@ -80,8 +80,9 @@ class Monitor(object):
         tunable_params = model.build(negatives=negatives)
         self.model = model
         self.grad_sync = None
-        if parallel.active():
-            self.grad_sync = parallel.GradSync()
+        if parallel.active() or parallel.shadow() is not None:
+            # `running.comm_overlap`: block (default: each block's bucket is reduced while the blocks below run their backward) | step
+            self.grad_sync = parallel.GradSync(overlap=str(cfg.running.get("comm_overlap", "block")))
             for head in (model.audio_head, model.image_head, model.text_head):
                 if head is not None and hasattr(head, "encoder"):
                     head.encoder.grad_sync = self.grad_sync

@@ -11,6 +11,14 @@ the CPU tests).  The path shards by samples; there are exactly two exchange step
      `logit_scale` is different: every rank computes its complete gradient, so it is never reduced in
      global-negatives mode.
 
+     `running.comm_overlap` picks when the buckets go out: "block" (default) -- each block's bucket as soon as it is complete,
+     overlapping the backward of the blocks below; "step" -- all of a step's block buckets as ONE all-reduce after the backward
+     (nothing shares the chip with the backward, the reduction is exposed).  DESIGN.md section 6 has the numbers behind the default.
+
+VIPANT_COMM_SHADOW=nwg[:min_us] (one process, no group): every bucket hand-over launches `vipant_comm_shadow` on the side stream
+instead of a collective -- nwg workgroups copying the bucket, each holding its CU for at least min_us -- so that the cost of sharing
+the chip with the reduction's kernel can be measured on one GPU (tools/comm_shadow.py, profiles/r5_comm_shadow.md).
+
 Device-agnostic on purpose: the same code runs under gloo on CPU tensors in tests/test_parallel_cpu.py.
 """
 from __future__ import annotations
@@ -32,6 +40,15 @@ def world_size() -> int:
 
 def rank() -> int:
     return dist.get_rank() if is_dist() else 0
+
+
+def shadow():
+    """(workgroups, microseconds) of the single-GPU stand-in for the bucket all-reduce, or None (VIPANT_COMM_SHADOW=nwg[:min_us])."""
+    spec = os.environ.get("VIPANT_COMM_SHADOW", "")
+    if not spec or spec == "0":
+        return None
+    nwg, _, us = spec.partition(":")
+    return int(nwg), float(us or 0.0)
 
 
 def active() -> bool:
@@ -74,14 +91,19 @@ def all_gather_features(x1: torch.Tensor, x2: torch.Tensor):
 
 
 class GradSync:
-    """Asynchronous SUM all-reduce of gradient buckets on a side stream."""
+    """SUM all-reduce of gradient buckets on a side stream: per block, overlapping the backward (`overlap="block"`), or all of a
+    step's block buckets as one collective when the backward is over (`overlap="step"`)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, overlap: str = "block"):
+        assert overlap in ("block", "step"), overlap
         self.group = group
+        self.overlap = overlap
         self.handles: List = []
         self.buffers: List[torch.Tensor] = []
         self.pairs: List = []
+        self.deferred: List = []            # overlap == "step": (flat, views, params) held back until wait()
         self.stream: Optional[torch.cuda.Stream] = None
+        self._shadow_dst: Optional[torch.Tensor] = None
 
     def _comm_stream(self, device):
         if self.stream is None:
@@ -93,6 +115,27 @@ class GradSync:
         `flat` that are the gradients of `params`: autograd usually CLONES a gradient it is handed while other
         references to it exist, so after the reduction `wait()` copies the reduced slices over whatever tensor ended
         up in `param.grad`."""
+        if self.overlap == "step" and (active() or shadow() is not None):
+            self.deferred.append((flat, views, params))
+            return
+        self._start(flat, views, params)
+
+    def _start(self, flat: torch.Tensor, views=None, params=None):
+        sh = shadow()
+        if sh is not None and not active():
+            if flat.is_cuda:                       # the collective's stand-in: same stream hand-off, a copy kernel that holds CUs
+                from . import _ffi
+                comm = self._comm_stream(flat.device)
+                comm.wait_stream(torch.cuda.current_stream(flat.device))
+                if self._shadow_dst is None or self._shadow_dst.numel() < flat.numel():
+                    self._shadow_dst = torch.empty_like(flat)
+                nbytes = flat.numel() * flat.element_size() // 16 * 16
+                with torch.cuda.stream(comm):
+                    # min_us is quoted for one block's bucket of the ViT-B tower (28.4 MB); other sizes hold in proportion
+                    _ffi.call("vipant_comm_shadow", flat.data_ptr(), self._shadow_dst.data_ptr(), nbytes, sh[0],
+                              sh[1] * max(nbytes / 28.4e6, 0.05), comm.cuda_stream)
+                flat.record_stream(comm)
+            return
         if not active():
             return
         if views is not None:
@@ -129,6 +172,20 @@ class GradSync:
         A parameter can own several slices -- a siamese shared encoder runs the stack twice over the same weights, once per
         tower, and each run hands over its own bucket -- so the slices of one parameter are summed; the first one is
         installed as `.grad` by reference (no 352 MB copy-back per step), the rest are added to it."""
+        if self.deferred:                    # overlap == "step": one flat buffer, one collective; the views move into it
+            held, self.deferred = self.deferred, []
+            if len(held) == 1:
+                self._start(*held[0])
+            else:
+                flat = torch.cat([f for f, _, _ in held])
+                views, params, off = [], [], 0
+                for f, vs, ps in held:
+                    for v, p in zip(vs or [], ps or []):
+                        o = off + v.storage_offset() - f.storage_offset()
+                        views.append(flat[o:o + v.numel()].view(v.shape))
+                        params.append(p)
+                    off += f.numel()
+                self._start(flat, views, params)
         for h in self.handles:
             h.wait()
         if self.stream is not None:
