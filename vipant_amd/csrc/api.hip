@@ -34,10 +34,11 @@ extern "C" int32_t vipant_device_check(void) {
 }
 
 // The ticket block of a (device, stream) pair (common.h): allocated and zeroed on the pair's first persistent launch, kept for the
-// life of the process.  The kernels leave it zeroed, so nothing is done per launch.
-uint32_t* vipant_ticket_block(hipStream_t stream) {
+// life of the process.  Returns the counter set this launch uses and, in *other, the set it has to zero for the stream's next one.
+uint32_t* vipant_ticket_block(hipStream_t stream, uint32_t** other) {
+    struct Block { uint32_t* base; int turn; };
     static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, uint32_t*> blocks;
+    static std::map<std::pair<int, hipStream_t>, Block> blocks;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
         vipant_set_error("ticket block: hipGetDevice failed");
@@ -45,13 +46,18 @@ uint32_t* vipant_ticket_block(hipStream_t stream) {
     }
     std::lock_guard<std::mutex> lock(mu);
     auto it = blocks.find({dev, stream});
-    if (it != blocks.end()) return it->second;
-    uint32_t* p = nullptr;
-    if (hipMalloc((void**)&p, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(p, 0, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        vipant_set_error("ticket block: allocation of %zu bytes failed", VIPANT_TICKET_WORDS * sizeof(uint32_t));
-        return nullptr;
+    if (it == blocks.end()) {
+        uint32_t* p = nullptr;
+        if (hipMalloc((void**)&p, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(p, 0, VIPANT_TICKET_WORDS * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            vipant_set_error("ticket block: allocation of %zu bytes failed", VIPANT_TICKET_WORDS * sizeof(uint32_t));
+            return nullptr;
+        }
+        it = blocks.emplace(std::make_pair(dev, stream), Block{p, 0}).first;
     }
-    blocks[{dev, stream}] = p;
-    return p;
+    Block& b = it->second;
+    uint32_t* mine = b.base + 8 * b.turn;
+    *other = b.base + 8 * (b.turn ^ 1);
+    b.turn ^= 1;
+    return mine;
 }

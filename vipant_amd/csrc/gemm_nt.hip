@@ -32,6 +32,7 @@ struct GemmNT {
     // ping-pong kernel only: the stream's ticket block (common.h) -- tiles beyond a workgroup's first two are drawn from its XCD's
     // queue instead of the static stride; NULL: static walk
     uint32_t* tk = nullptr;
+    uint32_t* tk_other = nullptr;      // the stream's other counter set: zeroed by this launch for the next one
 };
 
 template <int EPI>
@@ -562,9 +563,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
     const int nk = p.K / (ES == 2 ? BK : 2 * BK);
-    // Ticket walk (common.h; the host sets p.tk only for a full grid whose every queue is longer than two rounds).  A workgroup's
-    // first two tiles are the static walk's (positions b >> 3 and 32 + (b >> 3) of queue b & 7: nothing to wait for at start-up); from
-    // the third on, positions come from the queue's counter.  The stream needs a tile's successor one tile ahead, the LDS is full
+    // Ticket walk (common.h; the host sets p.tk only for a full grid whose every queue is longer than three rounds).  A workgroup's
+    // first three tiles are the static walk's (positions b >> 3, + 32, + 64 of queue b & 7: nothing to wait for at start-up); from
+    // the fourth on, positions come from the queue's counter.  The stream needs a tile's successor one tile ahead, the LDS is full
     // and `vmcnt` retires in order (anything slow in front of the counted LDS-DMA waits stalls them), so a ticket travels without a
     // wait of its own: wave 0 draws it at the START of an epilogue (the atomic has the whole epilogue to return), holds it until
     // the next tile's bias round trip (the one full wait a tile has anyway: the value is there), writes it to the workgroup's
@@ -585,16 +586,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         qlen_own = (ntiles >> 8) * 32 + rem;
     }
     uint32_t* const mbox = dyn ? p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x : nullptr;
-    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 64 + value)
+    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 96 + value)
     bool tk_dry = false;                        // thread 0: the queue is empty, stop drawing
     int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
+    bool tk_first = true;                       // the first tile's round trip has nothing to read: its "ticket" is the third static tile
     auto tk_tile = [&](uint32_t drawn) {
-        const int pos = 64 + (int)drawn;
+        const int pos = 96 + (int)drawn;
         if (pos < qlen_own) return tickets::tile_of(xq, pos);
         tk_dry = true;
         return NO_TILE;
     };
-    if (dyn && tid == 0) tk_pend = tickets::take(p.tk + xq, 2u);      // tiles 2 and 3 of this workgroup
+    if (dyn && tid == 0) {
+        tk_pend = tickets::take(p.tk + xq);     // this workgroup's fourth tile; not awaited before the first tile's bias round trip
+        // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
+        // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
+        if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
+    }
 
     // DMA: wave fills row blocks wave*4 .. wave*4+3 (8 rows x 128 B) of the tile's A and B rows, as in the kernel above
     uint32_t voffA[2], voffB[2];
@@ -783,15 +790,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     }
-    if (dyn && tid == 0) {       // (the draw returned with the prologue's loads)
-        tickets::put(mbox, (uint32_t)tk_tile(tk_pend));
-        tk_pend += 1u;
-    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the lag: group 1 runs one barrier interval behind group 0
 
+    // (tk_next, tk_post: the destination of the mailbox load and the data register of the mailbox store live across the whole walk --
+    // the kernel's last statement reads them.  hipcc protects a register that a load / store in flight still names with a vmcnt wait
+    // in front of its next writer: a wait behind LDS-DMA pieces or code loads wherever the allocator happened to reuse it.)
+    uint32_t tk_next = 0u, tk_post = 0u;
     while (tile < ntiles) {
-        uint32_t tk_next = 0u;
+        int tk_next_s = NO_TILE;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -802,20 +809,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         for (int k = 0; k < nk; ++k) {
             const int stage = gk & 1;
             const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+            // the ticket of the tile after the next: read one K-tile ahead of the bias round trip, which then finds it landed (a CU's
+            // memory pipeline is in order: read IN that round trip, the load waits behind the DMA pieces in flight, +0.9 us per
+            // tile on the launches without a bias)
+            if (dyn && k == nk - 2) tk_next = tickets::peek(mbox + tk_par);
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
-                if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);    // not awaited here
                 if (ES == 1) load_scales(nxt, sav_n, sbv_n);                  // the next tile's scales ride the same round trip
-                if (dyn) tk_next = tickets::get(mbox + tk_par);               // and so does the ticket of the tile after the next
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
                 if (ES == 1) asm volatile("" : "+v"(sav_n[0]), "+v"(sav_n[1]), "+v"(sbv_n));
+                if (dyn) {      // older than the loads above: awaited with them, and kept as a scalar from here (a vector register that
+                    asm volatile("" : "+v"(tk_next));     // "may be pending" costs a vmcnt wait behind the epilogue's stores)
+                    tk_next_s = __builtin_amdgcn_readfirstlane((int)tk_next);
+                }
                 if (dyn) {
-                    asm volatile("" : "+v"(tk_next));
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
-                    if (tid == 0) tickets::put(mbox + (tk_par ^ 1), (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend)));
+                    tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
+                    if (tid == 0) tickets::post(mbox + (tk_par ^ 1), tk_post);
                     tk_par ^= 1;
                 }
+                // (issued behind the waits above -- the code bytes come from HBM -- and not awaited here)
+                if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);
             }
             if (DEEP) {
                 // interval 0 (row tiles 0-3): B rows of K-tile k+2 (its slot was last read one interval ago by the lagging group),
@@ -879,13 +894,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(p.tk + xq);        // not awaited here
         pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile = tile_nxt;
-        tile_nxt = dyn ? __builtin_amdgcn_readfirstlane((int)tk_next) : tile_nxt + G;
+        tile_nxt = (dyn && !tk_first) ? tk_next_s : tile_nxt + G;
+        tk_first = false;
         cur = nxt;
         nxt = describe(tile_nxt);
         if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; sbv = sbv_n; }
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
-    if (dyn && tid == 0) tickets::finish(p.tk, gridDim.x);      // every draw of this workgroup has returned (tk_dry, or published)
+    if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
 }
 
 template <int EPI, int VAR, int ES = 2>
@@ -899,13 +915,13 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     const int64_t ntm = ceil_div(p.M, BM), ntn = ceil_div(p.N, BN);
     const int64_t tiles = ntm * ntn;
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
-    // ticket walk (common.h) when every XCD's queue holds more than the two rounds a workgroup takes statically: the shortest queue
+    // ticket walk (common.h) when every XCD's queue holds more than the three rounds a workgroup takes statically: the shortest queue
     // of the plain walk is the last one, of the column-grouped walk (VAR 8) the one of the last row quarter
     const int64_t ppx = (ntm + 3) / 4;
     const int64_t shortest = VAR == 8 ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
                                       : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
-    if (grid == 256 && shortest > 64 && !(p.dbg & 4194304)) {          // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
-        p.tk = vipant_ticket_block(stream);
+    if (grid == 256 && shortest > 96 && !(p.dbg & 4194304)) {          // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
+        p.tk = vipant_ticket_block(stream, &p.tk_other);
         if (p.tk == nullptr) return VIPANT_EHIP;
     }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
