@@ -152,20 +152,25 @@ int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const i
  * projection of every token (nn.MultiheadAttention's in_proj, clip/model.py:170-187 via cvap/module/val.py:519-522) is never formed.
  * qk bf16 [batch*H, D]: row (i, h) = W_k,h^T q_(i,h);  ctx bf16 [batch*H, D]: row (i, h) = sum_j p_j h1[i, j, :];
  * probs fp32 [batch, H, S] as above.  H = 8, 12 or 16 heads of 64 (D = 64 H); S <= 1024 (an item's raw scores wait
- * in LDS beside the staged rows: 64 KiB at H = 16). */
+ * in LDS beside the staged rows: 64 KiB at H = 16).
+ * pair != 0 (round 5, the step's default): qk, ctx (and dqk below; not dctx) are bf16 PAIRS, x = hi + lo, stored as two planes
+ * [2][batch*H, D] (hi plane first): these per-(item, head) vectors carry 16 instead of 8 mantissa bits between the kernels that
+ * produce and consume them, so the folded form adds no rounding the reference's attention does not have. */
 int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_t* idx, uint16_t* ctx, float* probs, int64_t batch,
-                            int64_t S, int64_t H, int32_t causal, void* stream);
+                            int64_t S, int64_t H, int32_t causal, int32_t pair, void* stream);
 /* dctx bf16 [batch*H, D]: row (i, h) = W_v,h^T dout_(i,h).  dh1 bf16 [batch*S, D]: the attention's gradient for EVERY token's h1 row
  * (zeros behind a causal limit; all rows written);  dqk bf16 [batch*H, D]: gradient of qk. */
 int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1, const int64_t* idx,
                             const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S, int64_t H, int32_t causal,
-                            void* stream);
+                            int32_t pair, void* stream);
 /* H independent products in one launch, C_h[M, N] = A_h[M, K] . B_h[N, K]^T (+ bias_h), bf16 in and out, operand h starting
  * h * stride elements behind operand 0: the per-head contractions of the folded form (a head's 64 columns of the `batch` read-out
- * rows against that head's block of W_k / W_v, and back) without the block-sparse [batch * H, D] operand of vipant_head_expand. */
-int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, const uint16_t* B, int64_t ldb, int64_t stride_b,
-                             uint16_t* C, int64_t ldc, int64_t stride_c, const float* bias, int64_t stride_bias, int64_t M, int64_t N,
-                             int64_t K, int64_t H, void* stream);
+ * rows against that head's block of W_k / W_v, and back) without the block-sparse [batch * H, D] operand of vipant_head_expand.
+ * a_lo / c_lo != 0: A / C is a bf16 pair (see vipant_rows_ctx_fwd) whose lo plane lies a_lo / c_lo elements behind the hi plane: a
+ * pair in A contributes both planes to the product, a pair in C receives bf16(acc) and bf16(acc - hi). */
+int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, int64_t a_lo, const uint16_t* B, int64_t ldb,
+                             int64_t stride_b, uint16_t* C, int64_t ldc, int64_t stride_c, int64_t c_lo, const float* bias,
+                             int64_t stride_bias, int64_t M, int64_t N, int64_t K, int64_t H, void* stream);
 /* rows bf16 [n, 64 H] -> out bf16 [n*H, 64 H]: row (i, h) = row i with every column outside head h's 64 zeroed -- the operand that
  * makes "per-head slice times the head's weight block" one dense contraction.  The step uses it for the two weight gradients of
  * the folded form (dW_v = expand(do)^T ctx, dW_k = expand(q)^T dqk through vipant_gemm_tn); the activations' products go through

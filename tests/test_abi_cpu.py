@@ -105,3 +105,38 @@ def test_no_kernel_spills_registers():
     assert not bad, bad
     n = sum(len(v) for v in usage.values())
     assert n > 200, n
+
+
+def test_streamed_attention_backward_does_not_touch_v_fragments_before_their_wait():
+    """mha_bwd1s_kernel requests the NEXT problem's V fragments with inline-asm `global_load_dwordx4` into AGPRs (`"=&a"`) and
+    awaits them a stage later with a hand-counted `s_waitcnt vmcnt(22)`.  The compiler cannot see that dependency: if it ever moved
+    or read one of those registers in between, dK / dV would be silently wrong.  Checked on the shipped build's own assembly: between
+    the last of the ten loads and the counted wait no instruction names any of the loaded AGPRs."""
+    from vipant_amd import build
+    build.build(verbose=False)
+    path = build.isa_path("attention.hip")
+    assert os.path.exists(path), path
+    text = open(path).read()
+    m = re.search(r"^(_ZN\S*mha_bwd1s_kernelILi20E\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M)
+    assert m, "mha_bwd1s_kernel<20> not found in the kept assembly"
+    lines = m.group(2).split("\n")
+    waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt\s+vmcnt\(22\)", l)]
+    assert len(waits) == 1, waits
+
+    def agprs(line):
+        regs = set()
+        for lo, hi in re.findall(r"\ba\[(\d+):(\d+)\]", line):
+            regs.update(range(int(lo), int(hi) + 1))
+        regs.update(int(r) for r in re.findall(r"\ba(\d+)\b", line))
+        return regs
+
+    loads = [i for i in range(waits[0]) if re.search(r"global_load_dwordx4\s+a\[", lines[i])]
+    group = loads[-10:]
+    assert len(group) == 10 and group[-1] - group[0] < 200, (len(loads), group)      # the in-loop v_load(pn): ten loads back to back
+    loaded = set().union(*(agprs(lines[i].split(",")[0]) for i in group))
+    assert len(loaded) == 40, sorted(loaded)
+    for i in range(group[0], waits[0]):
+        if i in group or lines[i].lstrip().startswith(";"):
+            continue
+        hit = agprs(lines[i]) & loaded
+        assert not hit, (i, lines[i].strip(), sorted(hit))

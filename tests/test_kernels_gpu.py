@@ -465,25 +465,37 @@ def test_mha_rows(ops, batch, S, H, causal, with_idx):
     assert float(qr.grad[:, :D][mask].abs().max()) == 0.0        # the premise: no query gradient off the read-out rows
 
 
+@pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("batch,S,H,causal,with_idx", [(3, 316, 12, False, False), (4, 77, 8, True, True), (2, 50, 12, False, True),
                                                        (3, 257, 16, False, False), (2, 5, 8, True, True), (2, 645, 12, False, False),
+                                                       (3, 77, 8, True, False),          # causal, no row index: row 0, one key
                                                        (1, 1024, 16, False, False)])     # the longest item the kernels take (LDS)
-def test_rows_ctx(ops, batch, S, H, causal, with_idx):
+def test_rows_ctx(ops, batch, S, H, causal, with_idx, pair):
     """The one-query attention of the last block with the K / V projection folded into the query side (csrc/readout_ctx.hip) against
-    its definition in fp64 autograd: contexts, softmax rows, dh1 of every token, dqk."""
+    its definition in fp64 autograd: contexts, softmax rows, dh1 of every token, dqk.  pair = 1 (the step's form, round 5): qk, the
+    contexts and dqk are bf16 pairs hi + lo -- the contexts and dqk must then be good to 2^-15 of their scale, not 2^-8; pair = 0:
+    single bf16 planes."""
     D = H * 64
     g = torch.Generator(device="cpu"); g.manual_seed(7)
     idx = torch.randint(0, S, (batch,), generator=g).to(DEV) if with_idx else None
     if with_idx and causal:
         idx[0] = S - 1; idx[1] = 0          # the whole sequence / a single key
-    qk = rnd(batch * H, D, seed=1, dtype=torch.bfloat16, scale=0.35)
+    def planes(x32):           # fp32 -> the operand as the kernels take it: [2, n, D] hi / lo planes, or one bf16 plane
+        hi = x32.to(torch.bfloat16)
+        return torch.stack([hi, (x32 - hi.float()).to(torch.bfloat16)]) if pair else hi
+
+    def value(t):              # ... and back to one fp64 tensor
+        return (t[0].double() + t[1].double()) if pair else t.double()
+
+    shape = (2, batch * H, D) if pair else (batch * H, D)
+    qk = planes(rnd(batch * H, D, seed=1, scale=0.35))
     h1 = rnd(batch * S, D, seed=2, dtype=torch.bfloat16)
-    ctx = torch.full((batch * H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    ctx = torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
     probs = torch.full((batch, H, S), 7.0, dtype=torch.float32, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     ip = idx.data_ptr() if idx is not None else None
-    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S, H, int(causal), st)
-    qd = qk.double().view(batch, H, D).requires_grad_()
+    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S, H, int(causal), pair, st)
+    qd = value(qk).view(batch, H, D).requires_grad_()
     hd = h1.double().view(batch, S, D).requires_grad_()
     sc = torch.einsum("bhd,bsd->bhs", qd, hd) / 8.0
     if causal:
@@ -492,18 +504,23 @@ def test_rows_ctx(ops, batch, S, H, causal, with_idx):
     pd = torch.softmax(sc, -1)
     ref = torch.einsum("bhs,bsd->bhd", pd, hd)
     assert_close(probs, pd, 2e-3, 1e-5, "rows_ctx softmax rows")
-    assert_close(ctx.view(batch, H, D), ref, 1e-2, 1e-2, "rows_ctx contexts")
+    # the probabilities enter the context product as bf16 (as in the reference-shaped attention kernels): 2^-9 each, averaged over the
+    # keys; the pair removes the OUTPUT rounding, so its error budget is the product's alone
+    assert_close(value(ctx).view(batch, H, D), ref, 3e-3 if pair else 1e-2, 3e-3 if pair else 1e-2, "rows_ctx contexts")
     dctx = rnd(batch * H, D, seed=3, dtype=torch.bfloat16)
     ref.backward(dctx.double().view(batch, H, D))
     dh1 = torch.full((batch * S, D), 7.0, dtype=torch.bfloat16, device=DEV)
-    dqk = torch.full((batch * H, D), 7.0, dtype=torch.bfloat16, device=DEV)
+    dqk = torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
     ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), ip, probs.data_ptr(), dh1.data_ptr(),
-             dqk.data_ptr(), batch, S, H, int(causal), st)
+             dqk.data_ptr(), batch, S, H, int(causal), pair, st)
     assert_close(dh1.view(batch, S, D), hd.grad, 2e-2, 2e-2 * hd.grad.abs().max().item(), "rows_ctx dh1")
-    assert_close(dqk.view(batch, H, D), qd.grad, 2e-2, 2e-2 * qd.grad.abs().max().item(), "rows_ctx dqk")
+    assert_close(value(dqk).view(batch, H, D), qd.grad, 2e-2, 2e-2 * qd.grad.abs().max().item(), "rows_ctx dqk")
+    if pair:        # the lo plane is what the hi plane's rounding left: |lo| <= 2^-8 |hi| elementwise, and not identically zero
+        assert float((dqk[1].float().abs() - 2.0 ** -8 * dqk[0].float().abs()).max()) <= 1e-30 and float(dqk[1].float().abs().max()) > 0
+        assert float((ctx[1].float().abs() - 2.0 ** -8 * ctx[0].float().abs()).max()) <= 1e-30 and float(ctx[1].float().abs().max()) > 0
     if S == 1024:
         with pytest.raises(Exception):      # one token more: refused (the caller takes the K / V form)
-            ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S + 1, H, int(causal), st)
+            ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S + 1, H, int(causal), pair, st)
     if causal:          # rows behind the limit get exact zeros, not the fill
         lim = idx if idx is not None else torch.zeros(batch, dtype=torch.long, device=DEV)
         behind = torch.arange(S, device=DEV).view(1, S) > lim.view(batch, 1)
@@ -531,6 +548,14 @@ def test_gemm_nt_heads(ops, n, H):
     old = ops.head_extract(ops.gemm_nt(wide, w[2 * D:], torch.empty((n * H, D), dtype=torch.bfloat16, device=DEV), bias=bias), H)
     assert_close(back, old, 2 ** -7, 2e-3, "wide_to_heads vs the block-sparse form")
     assert_close(ops.wide_to_heads(wide, w[2 * D:], H), ref - bias, 1e-2, 2e-2, "wide_to_heads, no bias")
+    # round 5: the [n * H, D] side as a bf16 pair -- written as (bf16(acc), bf16(acc - hi)), read with both planes in the product
+    pw = ops.heads_to_wide(rows, wt[:, D:2 * D], torch.full((2, n * H, D), 7.0, dtype=torch.bfloat16, device=DEV), H)
+    assert torch.equal(pw[0], wide)
+    exact = torch.einsum("nhc,hcd->nhd", rows.double().view(n, H, 64), w[D:2 * D].double().view(H, 64, D)).reshape(n * H, D)
+    assert_close(pw[0].double() + pw[1].double(), exact, 2.0 ** -14, 1e-4, "heads_to_wide, pair")
+    pb = ops.wide_to_heads(pw, w[2 * D:], H, bias=bias)
+    ref2 = torch.einsum("nhd,hcd->nhc", (pw[0].double() + pw[1].double()).view(n, H, D), w[2 * D:].double().view(H, 64, D)).reshape(n, D) + bias.double()
+    assert_close(pb, ref2, 2.0 ** -8, 2e-3, "wide_to_heads, pair in")
 
 
 def test_head_expand_extract(ops):
@@ -778,7 +803,8 @@ def test_round4_kernels_are_repeatable_under_load(ops):
     b, S, H = 96, 316, 12
     D = 64 * H
     st = torch.cuda.current_stream().cuda_stream
-    qk = rnd(b * H, D, seed=1, dtype=torch.bfloat16, scale=0.35); h1 = rnd(b * S, D, seed=2, dtype=torch.bfloat16)
+    qk32 = rnd(b * H, D, seed=1, scale=0.35); h1 = rnd(b * S, D, seed=2, dtype=torch.bfloat16)
+    qk = torch.stack([qk32.to(torch.bfloat16), (qk32 - qk32.to(torch.bfloat16).float()).to(torch.bfloat16)])      # a bf16 pair
     dctx = rnd(b * H, D, seed=3, dtype=torch.bfloat16)
     rows = rnd(512, D, seed=4, dtype=torch.bfloat16); w = rnd(3 * D, D, seed=5, dtype=torch.bfloat16, scale=D ** -0.5)
     wt = w.t().contiguous(); bias = rnd(D, seed=6)
@@ -790,15 +816,15 @@ def test_round4_kernels_are_repeatable_under_load(ops):
         if it % 2:
             with torch.cuda.stream(side):
                 hog_dst.copy_(hog_src)
-        ctx = torch.empty(b * H, D, dtype=torch.bfloat16, device=DEV); probs = torch.empty(b, H, S, device=DEV)
-        ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, ctx.data_ptr(), probs.data_ptr(), b, S, H, 0, st)
-        dh1 = torch.empty(b * S, D, dtype=torch.bfloat16, device=DEV); dqk = torch.empty(b * H, D, dtype=torch.bfloat16, device=DEV)
+        ctx = torch.empty(2, b * H, D, dtype=torch.bfloat16, device=DEV); probs = torch.empty(b, H, S, device=DEV)
+        ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, ctx.data_ptr(), probs.data_ptr(), b, S, H, 0, 1, st)
+        dh1 = torch.empty(b * S, D, dtype=torch.bfloat16, device=DEV); dqk = torch.empty(2, b * H, D, dtype=torch.bfloat16, device=DEV)
         ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
-                 dqk.data_ptr(), b, S, H, 0, st)
+                 dqk.data_ptr(), b, S, H, 0, 1, st)
         few = ops.gemm_nt(rows, w[:D], torch.empty(512, D, dtype=torch.bfloat16, device=DEV), bias=bias, few_rows=True)
         res = ops.gemm_nt(rows, w[:D], torch.empty(512, D, device=DEV), bias=bias, aux=x1[:, :1].expand(512, D).contiguous(),
                           epi=ops.EPI_RESIDUAL_F32, few_rows=True)
-        wide = ops.heads_to_wide(rows, wt[:, D:2 * D], torch.empty(512 * H, D, dtype=torch.bfloat16, device=DEV), H)
+        wide = ops.heads_to_wide(rows, wt[:, D:2 * D], torch.empty(2, 512 * H, D, dtype=torch.bfloat16, device=DEV), H)
         back = ops.wide_to_heads(wide, w[2 * D:], H, bias=bias)
         a_, t_ = x1.clone().requires_grad_(), x2.clone().requires_grad_()
         ls = torch.tensor(2.6593, device=DEV, requires_grad=True)

@@ -44,20 +44,21 @@ for name, fn, nbytes in (("fwd", fwd, 2 * b * S * D * 2), ("bwd", bwd, 4 * b * S
 
 # the same attention with the K / V projection folded into the query side (csrc/readout_ctx.hip): one pass over h1
 h1 = torch.randn(b * S, D, device=dev).to(torch.bfloat16)
-qk = (torch.randn(b * H, D, device=dev) * 0.35).to(torch.bfloat16)
-hctx = torch.empty(b * H, D, dtype=torch.bfloat16, device=dev)
+PAIR = int(os.environ.get("ROWS_PAIR", "1"))     # 1: qk / contexts / dqk as bf16 pairs (the step's form, round 5); 0: single planes
+qk = (torch.randn(2, b * H, D, device=dev) * torch.tensor([0.35, 0.35 / 256], device=dev).view(2, 1, 1)).to(torch.bfloat16)
+hctx = torch.empty(2, b * H, D, dtype=torch.bfloat16, device=dev)
 dctx = torch.randn(b * H, D, device=dev).to(torch.bfloat16)
 dh1 = torch.empty_like(h1)
 dqk = torch.empty_like(qk)
 
 
 def cfwd():
-    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, hctx.data_ptr(), probs.data_ptr(), b, S, H, 0, st)
+    ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, hctx.data_ptr(), probs.data_ptr(), b, S, H, 0, PAIR, st)
 
 
 def cbwd():
     ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
-             dqk.data_ptr(), b, S, H, 0, st)
+             dqk.data_ptr(), b, S, H, 0, PAIR, st)
 
 
 for name, fn, nbytes in (("fwd", cfwd, b * S * D * 2), ("bwd", cbwd, 2 * b * S * D * 2)):

@@ -31,8 +31,17 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-re
 # gemm_nt.hip, second option: the ticket walk draws a tile with ONE atomic add per workgroup whose result is needed a tile later; the
 # atomic optimizer rewrites a uniform atomic as "first active lane adds, s_waitcnt vmcnt(0), readfirstlane" -- a full wait (every
 # LDS-DMA piece in flight included) at the place where the draw is issued.
-EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"],
-                "attention_wide.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]}
+EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm"]}
+
+
+# files whose device assembly is kept beside the object (lib/obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s): kernels with hand-counted
+# `s_waitcnt vmcnt(n)` or inline-asm loads, whose correctness depends on what the compiler put between two instructions
+# (tests/test_abi_cpu.py reads it)
+KEEP_ISA = ("attention.hip",)
+
+
+def isa_path(name: str) -> str:
+    return os.path.join(OBJ, name[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
 _REMARK_ECHO = re.compile(r"^\s*(\d+ \||\|)")      # the source-line echo clang prints under each remark
@@ -84,7 +93,7 @@ def _older(target: str, deps) -> bool:
 
 
 def stale() -> bool:
-    return _older(LIB, sources() + _headers())
+    return _older(LIB, sources() + _headers()) or any(not os.path.exists(isa_path(n)) for n in KEEP_ISA)
 
 
 def _probe_flags():
@@ -111,11 +120,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     _probe_flags()
     hdrs = _headers()
-    todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs) or not os.path.exists(_obj(s)[:-2] + ".resources.json")]
+    todo = [s for s in sources() if force or _older(_obj(s), [s] + hdrs) or not os.path.exists(_obj(s)[:-2] + ".resources.json")
+            or (os.path.basename(s) in KEEP_ISA and not os.path.exists(isa_path(os.path.basename(s))))]
 
     def compile_one(src):
-        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(os.path.basename(src), []), "-Rpass-analysis=kernel-resource-usage", "-c", src,
-               "-o", _obj(src)]
+        base = os.path.basename(src)
+        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(base, []), "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", _obj(src)]
         if verbose:
             print("[vipant_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -127,6 +137,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise subprocess.CalledProcessError(r.returncode, cmd)
         with open(_obj(src)[:-2] + ".resources.json", "w") as f:
             json.dump(usage, f, indent=0)
+        if base in KEEP_ISA:     # the device assembly of the same flags, kept beside the object (isa_path)
+            subprocess.run([HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(base, []), "--cuda-device-only", "-S", src, "-o", isa_path(base)],
+                           stderr=subprocess.DEVNULL, check=True)
         for name, u in usage.items():
             if u.get("VGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0):
                 print(f"[vipant_amd.build] WARNING {os.path.basename(src)}: {name} spills "

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_bwd_dkv_kernel(MhaArgs p) {
 }
 
 
-// ------------------------------------------------------------------------ backward, ONE pass (round 3; S <= 320, no mask)
+// ------------------------------------------------------------------------ backward, ONE pass: the scheme (round 3; S <= 320, no mask)
 // The two passes above recompute S and dP twice (7 contractions, exp twice).  This kernel does the five contractions once:
 //     S^T = Q K^T, dP^T = dO V^T            (key on the MFMA column: this wave's key blocks are the register-resident B operands)
 //     dV^T += dO^T P, dK^T += Q^T dS        (the S^T / dP^T accumulators are, after exp and packing, already the B operands)
@@ -494,361 +494,9 @@ __device__ unsigned long long g_attn_stamps[64];
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void mha_bwd1_kernel(MhaArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SP = NT * 16, KPW = NT / 4, NU = NT / 2;
-    static_assert(NT % 4 == 0, "key blocks must split evenly over the four waves");
-    char* qimg = smem;
-    char* doimg = smem + SP * 128;
-    char* kimg = smem + 2 * SP * 128;
-    char* xbuf = smem + 3 * SP * 128;                 // X[2][SP][32] bf16, 64-byte rows
-    const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int D = p.H * 64, ld = 3 * D;
-    // Persistent (round 4): one workgroup per CU walks the (batch, head) problems.  A relaunched workgroup costs 1-3 us of start-up
-    // per problem (tools/attnw_trace.py on the forward), and with ONE workgroup per CU nothing runs on the CU meanwhile.
-    const int nprob = p.batch * p.H;
-  for (int prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
-    // (the lane index is laundered per problem: every per-lane address below is then recomputed here instead of being hoisted out
-    // of the problem loop and kept -- or spilled -- across a body that needs all 512 registers)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int tid = wave * 64 + lane;
-    const int kcol = lane & 15, g = lane >> 4;
-    const int b = prob / p.H, h = prob % p.H;
-    const int64_t row_base = (int64_t)b * p.S;
-
-    const bf16_t* base = p.qkv + row_base * ld + h * 64;
-    const int64_t remain = ((int64_t)(p.batch - b) * p.S * ld - h * 64) * 2;
-    const uint32_t lim = (uint32_t)(remain > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain);
-    const bf16_t* dobase = p.dout + row_base * D + h * 64;
-    const int64_t remain_o = ((int64_t)(p.batch - b) * p.S * D - h * 64) * 2;
-    const uint32_t lim_o = (uint32_t)(remain_o > 0xFFFFFFFFll ? 0xFFFFFFFFll : remain_o);
-    const int64_t stat0 = ((int64_t)b * p.H + h) * p.S;
-
-    STAMP(0);
-    // the three images first (LDS-DMA, 30 pieces per wave), then the register operands behind them in the same queue
-    dma_image(qimg, uniform_rsrc(base, lim), ld * 2, SP / 8, wave, 4, lane);
-    dma_image(doimg, uniform_rsrc(dobase, lim_o), D * 2, SP / 8, wave, 4, lane);
-    dma_image(kimg, uniform_rsrc(base + D, lim > (uint32_t)(D * 2) ? lim - D * 2 : 0), ld * 2, SP / 8, wave, 4, lane);
-    // O rows for delta = rowsum(dO * O): thread (row = tid >> 2 (+ 64 per pass), quarter = tid & 3) takes 16 of the 64 columns
-    constexpr int NP = SP / 64;
-    bf16x8 orow[NP][2];
-    {
-        const bf16_t* obase = p.out + row_base * D + h * 64;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = i * 64 + (tid >> 2);
-            const int64_t off = (int64_t)(row < p.S ? row : p.S - 1) * D + (tid & 3) * 16;
-            orow[i][0] = *(const bf16x8*)(obase + off);
-            orow[i][1] = *(const bf16x8*)(obase + off + 8);
-        }
-    }
-    // this wave's key blocks: wave, wave + 4, ...; their V rows as B-operand fragments (key on the lane) straight from HBM; the K
-    // fragments are read from the K image once it has landed (round 4: 40 KB less through the CU's load path per problem)
-    bf16x8 kf[KPW][2], vf[KPW][2];
-#pragma unroll
-    for (int j = 0; j < KPW; ++j) {
-        const int key = (wave + 4 * j) * 16 + kcol;
-        const bf16_t* kp = base + (int64_t)(key < p.S ? key : p.S - 1) * ld + 2 * D + 8 * g;  // rows >= S: a copy of row S - 1 (finite)
-        vf[j][0] = *(const bf16x8*)kp;
-        vf[j][1] = *(const bf16x8*)(kp + 32);
-    }
-    STAMP(1);
-    // the images are the oldest 30 entries of the queue: wait for them only, then take dO for delta from its LDS image
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 2 * KPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    STAMP(27);
-    // Keys >= S (the image rows behind the problem's last row hold the next sample's data): their P / dS are finite numbers, not
-    // zeros -- dK / dV rows of such keys are never stored, and zeroing their K rows removes them from the dQ^T product.
-    for (int i = p.S * 8 + tid; i < SP * 8; i += 256) *(u32x4*)(kimg + i * 16) = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int row = i * 64 + (tid >> 2), c0 = (tid & 3) * 2;
-        const bf16x8 d0 = *(const bf16x8*)(doimg + row * 128 + (((c0) ^ img_swz(row)) << 4));
-        const bf16x8 d1 = *(const bf16x8*)(doimg + row * 128 + (((c0 + 1) ^ img_swz(row)) << 4));
-        float sacc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sacc += (float)d0[e] * (float)orow[i][0][e] + (float)d1[e] * (float)orow[i][1][e];
-        sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        if ((tid & 3) == 0 && row < p.S) p.delta[stat0 + row] = sacc;
-    }
-    __syncthreads();                                   // delta visible to the workgroup (and the V fragments have landed)
-    const ImgLane il = img_lane(lane);
-#pragma unroll
-    for (int j = 0; j < KPW; ++j) {                    // keys >= S: zero rows -- finite P / dS that are never stored
-        kf[j][0] = img_row_frag(kimg, il, wave + 4 * j, 0);
-        kf[j][1] = img_row_frag(kimg, il, wave + 4 * j, 1);
-    }
-    // The resident operand fragments live in the ACCUMULATOR half of the register file (MFMA reads A / B operands from there as
-    // well): with dK / dV that half is full, so the S / dP products must take architectural VGPRs as their destination -- which is
-    // where the exp / dS arithmetic needs them (in AGPRs every score cost a v_accvgpr_read: 180 of 400 VALU instructions per step).
-#pragma unroll
-    for (int j = 0; j < KPW; ++j) {
-        asm volatile("" : "+a"(kf[j][0])); asm volatile("" : "+a"(kf[j][1]));
-        asm volatile("" : "+a"(vf[j][0])); asm volatile("" : "+a"(vf[j][1]));
-    }
-    STAMP(2);
-
-    // row statistics of a 32-query step through bounds-checked buffer loads (rows >= S read as 0 and are masked below)
-    const __amdgpu_buffer_rsrc_t rs_lse = uniform_rsrc(p.lse + stat0, (uint32_t)p.S * 4u);
-    const __amdgpu_buffer_rsrc_t rs_del = uniform_rsrc(p.delta + stat0, (uint32_t)p.S * 4u);
-    // dQ rows of this (batch, head): stores of rows >= S (and of the step before the first) go out of range and are dropped
-    const __amdgpu_buffer_rsrc_t rs_dq = uniform_rsrc(p.dqkv + row_base * ld + h * 64, (uint32_t)(((int64_t)(p.S - 1) * ld + 64) * 2));
-    auto load_rows = [&](int u, bf16x8 (&qr)[2][2], bf16x8 (&dr)[2][2]) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                qr[tt][ds] = img_row_frag(qimg, il, 2 * u + tt, ds);
-                dr[tt][ds] = img_row_frag(doimg, il, 2 * u + tt, ds);
-            }
-    };
-    auto load_tr = [&](int u, bf16x8 (&qtr)[4], bf16x8 (&dot)[4]) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { qtr[dt] = img_tr_frag(qimg, il, u, dt); dot[dt] = img_tr_frag(doimg, il, u, dt); }
-    };
-    auto load_stats = [&](int u, f32x4 (&nl)[2], f32x4 (&ndl)[2]) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int q0 = u * 32 + tt * 16 + g * 4;
-            const f32x4 lv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_lse, (uint32_t)q0 * 4u, 0, 0));
-            const f32x4 dv4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_del, (uint32_t)q0 * 4u, 0, 0));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nl[tt][r] = q0 + r < p.S ? -lv[r] * LOG2E : -INFINITY;
-                ndl[tt][r] = -dv4[r];
-            }
-        }
-    };
-    // exchange-buffer addressing.  Write: lane (key = kcol, g) owns queries 4g .. 4g+3 of tile tt of its key's row; the two 32-byte
-    // halves of a row are swapped on rows with bit 2 set, which makes the transposed reads below conflict-free.
-    const uint32_t xswz = (uint32_t)((kcol >> 2) & 1) * 32u;
-    const uint32_t xw0 = (uint32_t)(kcol * 64 + g * 8) + xswz, xw1 = (uint32_t)(kcol * 64 + g * 8) + (32u ^ xswz);
-    // Read (B operand of the dQ^T product, rows = keys 4g + qq (+16), columns = this wave's query tile): as img_tr_frag
-    const int qt2 = wave & 1, dtp = wave >> 1;         // phase 2: query tile wave & 1, d tiles 2 (wave >> 1), + 1
-    const int xra = 4 * g + ((lane >> 2) & 3);
-    const uint32_t xrd = (uint32_t)(xra * 64 + ((qt2 ^ (g & 1)) * 32) + (lane & 3) * 8);
-    const uint32_t ka0 = dtp ? il.tr[2] : il.tr[0], ka1 = dtp ? il.tr[3] : il.tr[1];
-    auto tr_pair = [&](const char* pa, uint32_t second) {
-        const bf16x4 lo = lds_read_tr16(pa);
-        const bf16x4 hi = lds_read_tr16(pa + second);
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
-    };
-
-    f32x4 dk[KPW][4], dv[KPW][4];
-#pragma unroll
-    for (int j = 0; j < KPW; ++j)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    // ---- the software pipeline.  One wave per SIMD: nothing but program order overlaps the matrix pipe with the VALU, so the
-    // stages of consecutive key blocks are issued skewed: region j of a step holds the exp / dS arithmetic of key block j (V),
-    // the S / dP products of block j + 1 (S) and the dV / dK products of block j - 1 (A) -- 16 MFMAs that do not depend on the
-    // VALU work beside them -- plus a slice of the previous step's dQ^T product (P: LDS + MFMA only).  The last block's A stage
-    // runs at the head of the NEXT step, beside that step's first S stage.
-    bf16x8 qr[2][2], dr[2][2], qtr[4], dot[4];
-    f32x4 nl[2], ndl[2], nl_n[2], ndl_n[2];
-    f32x4 sa[2][2], dp[2][2];                          // [parity of the key-block index][query tile]
-    f32x4 p2[2], ds2[2];                               // P and dS of the key block in its V stage
-    bf16x8 pf_c, dsf_c;                                // P / dS fragments waiting for their A stage
-    f32x4 dq0, dq1;                                    // dQ^T tile pair of the previous step
-    bf16x8 xfa, k0a, k1a, xfb, k1b, k0b;               // operand fragments of the region's slice of the dQ^T product
-    // the i-th MFMA (0..7) of the S stage of key block j: query tile i >> 2; S chain (Q rows x K) and dP chain (dO rows x V) alternate
-    auto s_mfma = [&](auto jc, auto ic) {
-        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, par = j & 1;
-        if ((i & 3) == 0) sa[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[tt][0], kf[j][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if ((i & 3) == 1) dp[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[tt][0], vf[j][0], ndl[tt], 0, 0, 0);
-        if ((i & 3) == 2) sa[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[tt][1], kf[j][1], sa[par][tt], 0, 0, 0);
-        if ((i & 3) == 3) dp[par][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[tt][1], vf[j][1], dp[par][tt], 0, 0, 0);
-    };
-    auto a_mfma = [&](auto jc, auto ic) {
-        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, dt = i >> 1;
-        if (i & 1) dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf_c, dk[j][dt], 0, 0, 0);
-        else dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pf_c, dv[j][dt], 0, 0, 0);
-    };
-    auto p_mfma = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (i == 0) dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0a, xfa, dq0, 0, 0, 0);
-        if (i == 1) dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1a, xfa, dq1, 0, 0, 0);
-        if (i == 2) dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0b, xfb, dq0, 0, 0, 0);
-        if (i == 3) dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1b, xfb, dq1, 0, 0, 0);
-    };
-    auto p_load = [&](auto ic, const char* xr, int uk) {          // piece i (0..5) of the fragments of key steps uk, uk + 1
-        constexpr int i = decltype(ic)::value;
-        if (i == 0) xfa = tr_pair(xr + uk * 2048, 1024);
-        if (i == 1) k0a = tr_pair(kimg + ka0 + uk * 4096, 2048);
-        if (i == 2) k1a = tr_pair(kimg + ka1 + uk * 4096, 2048);
-        if (i == 3) xfb = tr_pair(xr + (uk + 1) * 2048, 1024);
-        if (i == 4) k0b = tr_pair(kimg + ka0 + (uk + 1) * 4096, 2048);
-        if (i == 5) k1b = tr_pair(kimg + ka1 + (uk + 1) * 4096, 2048);
-    };
-    // the arithmetic of score element i (query tile i >> 2, register i & 3) of key block j in three stages, issued one group apart
-    // so that no group holds a dependent chain (one wave per SIMD: a dependent VALU pair stalls the whole SIMD):
-    //   F: t = S * c2 - lse     E: p = exp2(t)     M: dS = p * (dP - delta)
-    float tf[2];                                       // [element parity]
-    auto v_f = [&](auto jc, auto ic) {
-        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, r = i & 3, par = j & 1;
-        tf[i & 1] = sa[par][tt][r] * C2 + nl[tt][r];
-    };
-    auto v_e = [&](auto ic) {
-        constexpr int i = decltype(ic)::value, tt = i >> 2, r = i & 3;
-        p2[tt][r] = __builtin_amdgcn_exp2f(tf[i & 1]);
-    };
-    auto v_m = [&](auto jc, auto ic) {
-        constexpr int j = decltype(jc)::value, i = decltype(ic)::value, tt = i >> 2, r = i & 3, par = j & 1;
-        ds2[tt][r] = p2[tt][r] * dp[par][tt][r];        // dp already holds dP - delta; the 1/sqrt(d) factor goes to dq / dk
-    };
-    auto dq_store = [&](int u, bool on) {
-        const int q = u * 32 + qt2 * 16 + kcol;
-        const uint32_t off = (on && q < p.S) ? (uint32_t)(((int64_t)q * ld + dtp * 32 + g * 4) * 2) : 0xFFFFFFF0u;
-        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x4_to_bf16x4(dq0 * SCALE)), rs_dq, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, f32x4_to_bf16x4(dq1 * SCALE)), rs_dq, off, 32, 0);
-    };
-    // One region = ten issue groups, fenced so that the order survives the scheduler: group gi holds MFMAs 2 gi, 2 gi + 1 of the
-    // region's list [S of block J + 1 | A of block J - 1 | dQ^T slice], the arithmetic of score element gi of block J (two tiles
-    // x four registers; the packing and the exchange-buffer writes in groups 8 and 9) and one piece of the dQ^T slice's fragment
-    // reads.  Two MFMAs keep the matrix pipe busy for 32 cycles; an element's five VALU instructions issue in about 28.
-    auto region = [&](auto jc, int u, char* xw, const char* xr) {
-        constexpr int J = decltype(jc)::value;
-        constexpr int nS = J + 1 < KPW ? 8 : 0, nA = J >= 1 ? 8 : 0;
-        bf16x8 pf_n, dsf_n;
-        auto mfma_n = [&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            if constexpr (n < nS) s_mfma(Int2<(J + 1 < KPW ? J + 1 : 0)>{}, Int2<(n < nS ? n : 0)>{});
-            else if constexpr (n < nS + nA) a_mfma(Int2<(J >= 1 ? J - 1 : 0)>{}, Int2<(n - nS) & 7>{});
-            else if constexpr (n < nS + nA + 4) p_mfma(Int2<(n - nS - nA) & 3>{});
-        };
-        auto group = [&](auto gc) {
-            constexpr int gi = decltype(gc)::value;
-            if constexpr (gi < 6) p_load(Int2<gi>{}, xr, 2 * J);
-            mfma_n(Int2<2 * gi>{});
-            __builtin_amdgcn_sched_barrier(0);         // M V M V: two adjacent MFMAs would leave the issue port idle for half of the first
-            if constexpr (gi < 8) v_e(Int2<(gi < 8 ? gi : 0)>{});
-            if constexpr (gi >= 1 && gi <= 8) v_m(jc, Int2<(gi >= 1 && gi <= 8 ? gi - 1 : 0)>{});
-            if constexpr (gi == 8) pf_n = pack8_pairs(p2[0], p2[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_n(Int2<2 * gi + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (gi < 7) v_f(jc, Int2<(gi < 7 ? gi + 1 : 0)>{});
-            if constexpr (gi == 9 && J + 1 < KPW) v_f(Int2<(J + 1 < KPW ? J + 1 : 0)>{}, Int2<0>{});   // the next block's first element
-            if constexpr (gi == 9) dsf_n = pack8_pairs(ds2[0], ds2[1]);
-            if constexpr (gi == 9) {
-                const u32x4 dw = __builtin_bit_cast(u32x4, dsf_n);
-                typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-                *(u32x2_t*)(xw + J * 4096 + xw0) = u32x2_t{dw[0], dw[1]};
-                *(u32x2_t*)(xw + J * 4096 + xw1) = u32x2_t{dw[2], dw[3]};
-                if (J == KPW - 1) load_rows(u + 1, qr, dr);         // the rows' last readers (S of the last block) are issued
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        group(Int2<0>{}); group(Int2<1>{}); group(Int2<2>{}); group(Int2<3>{}); group(Int2<4>{});
-        group(Int2<5>{}); group(Int2<6>{}); group(Int2<7>{}); group(Int2<8>{}); group(Int2<9>{});
-        pf_c = pf_n; dsf_c = dsf_n;
-    };
-
-    load_rows(0, qr, dr);
-    load_stats(0, nl, ndl);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { qtr[dt] = bf16x8{}; dot[dt] = bf16x8{}; }
-    pf_c = bf16x8{}; dsf_c = bf16x8{};
-    STAMP(3);
-    for (int u = 0; u < NU; ++u) {
-        STAMP(4 + 2 * u);
-        char* xw = xbuf + (u & 1) * (SP * 64) + wave * 1024;
-        const char* xr = xbuf + ((u & 1) ^ 1) * (SP * 64) + xrd;       // X of step u - 1
-        // head: the previous step's last A stage (zeros at u = 0), this step's transposed fragments, the first S stage
-        a_mfma(Int2<KPW - 1>{}, Int2<0>{}); a_mfma(Int2<KPW - 1>{}, Int2<1>{}); a_mfma(Int2<KPW - 1>{}, Int2<2>{}); a_mfma(Int2<KPW - 1>{}, Int2<3>{});
-        a_mfma(Int2<KPW - 1>{}, Int2<4>{}); a_mfma(Int2<KPW - 1>{}, Int2<5>{}); a_mfma(Int2<KPW - 1>{}, Int2<6>{}); a_mfma(Int2<KPW - 1>{}, Int2<7>{});
-        load_stats(u + 1, nl_n, ndl_n);                 // past the last step: zeros, unused
-        __builtin_amdgcn_sched_barrier(0);
-        load_tr(u, qtr, dot);
-        s_mfma(Int2<0>{}, Int2<0>{}); s_mfma(Int2<0>{}, Int2<1>{}); s_mfma(Int2<0>{}, Int2<2>{}); s_mfma(Int2<0>{}, Int2<3>{});
-        s_mfma(Int2<0>{}, Int2<4>{}); s_mfma(Int2<0>{}, Int2<5>{}); s_mfma(Int2<0>{}, Int2<6>{}); s_mfma(Int2<0>{}, Int2<7>{});
-        dq0 = f32x4{0.f, 0.f, 0.f, 0.f}; dq1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-        v_f(Int2<0>{}, Int2<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        static_assert(KPW == 5, "the region list below is written out for five key blocks per wave");
-        if (u == 5) STAMP(30);
-        region(Int2<0>{}, u, xw, xr);
-        if (u == 5) STAMP(31);
-        region(Int2<1>{}, u, xw, xr);
-        if (u == 5) STAMP(32);
-        region(Int2<2>{}, u, xw, xr);
-        if (u == 5) STAMP(33);
-        region(Int2<3>{}, u, xw, xr);
-        if (u == 5) STAMP(34);
-        region(Int2<4>{}, u, xw, xr);
-        if (u == 5) STAMP(35);
-        dq_store(u - 1, u > 0);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) { nl[tt] = nl_n[tt]; ndl[tt] = ndl_n[tt]; }
-        STAMP(5 + 2 * u);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    STAMP(24);
-    auto a_stage = [&](auto jc, const bf16x8& pf, const bf16x8& dsf) {
-        constexpr int j = decltype(jc)::value;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[dt], pf, dv[j][dt], 0, 0, 0);
-            dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, dk[j][dt], 0, 0, 0);
-        }
-    };
-    auto p_stage = [&](const char* xr, int uk0, int n) {
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            const int uk = uk0 + i;
-            const bf16x8 xf = tr_pair(xr + uk * 2048, 1024);
-            const bf16x8 k0 = tr_pair(kimg + ka0 + uk * 4096, 2048), k1 = tr_pair(kimg + ka1 + uk * 4096, 2048);
-            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, xf, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, xf, dq1, 0, 0, 0);
-        }
-    };
-    a_stage(Int2<KPW - 1>{}, pf_c, dsf_c);
-    dq0 = f32x4{0.f, 0.f, 0.f, 0.f}; dq1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    p_stage(xbuf + ((NU - 1) & 1) * (SP * 64) + xrd, 0, NU);
-    dq_store(NU - 1, true);
-    STAMP(25);
-    // dK / dV: through LDS (the Q / dO images are dead: 20 KiB of them per wave, no barrier needed) so that they leave as whole
-    // 128-byte rows, 16 B per lane, instead of 8-byte pieces at a row stride.  Row (key) = 256 B: dK | dV; 8-byte granules XOR-ed
-    // with an even number per key (conflict-free writes, and a 16-byte chunk stays a chunk).
-    {
-        char* stg = smem + wave * (KPW * 4096);
-#pragma unroll
-        for (int j = 0; j < KPW; ++j)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint32_t sw = (uint32_t)(kcol & 7) << 1;
-                *(bf16x4*)(stg + j * 4096 + kcol * 256 + (((uint32_t)(dt * 4 + g) ^ sw) << 3)) = f32x4_to_bf16x4(dk[j][dt] * SCALE);
-                *(bf16x4*)(stg + j * 4096 + kcol * 256 + (((uint32_t)(16 + dt * 4 + g) ^ sw) << 3)) = f32x4_to_bf16x4(dv[j][dt]);
-            }
-#pragma unroll
-        for (int j = 0; j < KPW; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kr_ = i * 4 + (lane >> 4), c = lane & 15;
-                const int key = (wave + 4 * j) * 16 + kr_;
-                const bf16x8 v = *(const bf16x8*)(stg + j * 4096 + kr_ * 256 + ((c ^ (kr_ & 7)) << 4));
-                if (key < p.S)
-                    *(bf16x8*)(p.dqkv + (row_base + key) * ld + D + h * 64 + (c >> 3) * D + (c & 7) * 8) = v;
-            }
-    }
-    STAMP(26);
-    __syncthreads();                                   // every wave has read its staging rows: the next problem's images may land
-  }
-}
-
 // ------------------------------------------------------------------------ backward, ONE pass, streamed operands (round 4)
-// The same five contractions, the same regions and issue groups as mha_bwd1_kernel; what changes is where the operands wait.  There a
+// The five contractions, regions and issue groups of the scheme above (round 3's kernel with resident Q / dO / K images is kept as
+// text: tools/probes/mha_bwd1_resident.hip.txt); what changed in round 4 is where the operands wait.  There a
 // problem began with 200 KB of loads (Q, dO, K images, K / V fragments) that nothing overlapped -- one workgroup per CU, 13-16 k of
 // 61 k cycles -- because the three images filled the LDS.  Only one 32-query step's rows of Q and dO are ever read at a time, so here
 // they pass through a ring of four 8-KiB stages, requested three steps ahead; the LDS that frees holds a SECOND K image, filled one
@@ -1567,16 +1215,10 @@ int32_t launch_stream(const MhaArgs& a, hipStream_t s) {
 template <int NT>
 int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s);
 
-// VIPANT_ATTN_BWD=2: the two-pass backward (round 2) for A/B timing; VIPANT_ATTN_STAGGER: see mha_bwd1_kernel
-int attn_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-int attn_waves() {
-    static const int nw = getenv("VIPANT_ATTN_WAVES") ? atoi(getenv("VIPANT_ATTN_WAVES")) : 8;
-    return nw == 4 ? 4 : 8;
-}
+// No environment switch selects a kernel here (round 5): every kernel in this file is the only one for its shapes, and
+// tests/test_kernels_gpu.py::test_mha reaches each of them -- forward (S <= 384), single-pass streamed backward (224 < S <= 320, no
+// mask), two-pass backward (causal / other S), streaming kernels (S > 384).  Variants that were measured and not kept are text
+// under tools/probes/ (mha_bwd1_resident, attention_wide, mha_fwd2_variant).
 
 template <int NT, bool CAUSAL, int NW, int EDGE>
 int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
@@ -1585,6 +1227,7 @@ int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done_on_device(once);
     }
     hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
     VIPANT_LAUNCH_CHECK();
@@ -1601,6 +1244,7 @@ int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd_dkv_kernel<NT, CAUSAL, NW, EDGE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        done_on_device(once);
     }
     hipLaunchKernelGGL((mha_bwd_dq_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds_a, s, a);
     VIPANT_LAUNCH_CHECK();
@@ -1610,38 +1254,14 @@ int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
 }
 
 template <int NT>
-int32_t launch_bwd1(const MhaArgs& a, hipStream_t s) {
-    constexpr int lds = NT * 8192;
-    static DeviceOnce once;
-    if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
-    static int cus = 0;                              // one persistent workgroup per CU (all 160 KiB of LDS)
-    if (!cus) {
-        int dev = 0;
-        VIPANT_HIP_TRY(hipGetDevice(&dev));
-        VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const int nprob = a.batch * a.H;
-    const int grid = attn_env("VIPANT_ATTN_BWD_PERSIST", 1) ? (nprob < cus ? nprob : cus) : nprob;
-    hipLaunchKernelGGL((mha_bwd1_kernel<NT>), dim3(grid), dim3(256), lds, s, a);
-    VIPANT_LAUNCH_CHECK();
-    return VIPANT_OK;
-}
-
-
-template <int NT>
 int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024;
     static DeviceOnce once;
-    static int cus = 0;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int dev = 0;
-        VIPANT_HIP_TRY(hipGetDevice(&dev));
-        VIPANT_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        done_on_device(once);
     }
-    const int nprob = a.batch * a.H;
+    const int nprob = a.batch * a.H, cus = device_cus();       // one persistent workgroup per CU
     hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
@@ -1653,36 +1273,20 @@ int32_t launch_fwd(const MhaArgs& a, hipStream_t s) {
     // measured (tools/attn_bench.py, b=512 S=316): forward 4 / 5 / 6 / 8 waves = 330 / 461 / 403 / 360 us (the kernels are
     // LDS-instruction bound, more waves only add contention); backward is faster with 8
     const bool tight = a.S > (NT - 2) * 16;
-    if constexpr (NT == 20 && !CAUSAL) {
-        // round 4: VIPANT_ATTN_FWD=32 takes the audio tower's shape (288 < S <= 320) through the v_mfma_f32_32x32x16_bf16 kernel of
-        // attention_wide.hip (persistent, two image sets, software-pipelined): built, bit-for-bit as accurate, and measured equal to
-        // this file's 16x16x32 kernel (299-309 vs 297-307 us at b = 512), which therefore stays the default
-        static const int variant = attn_env("VIPANT_ATTN_FWD", 16);
-        if (variant == 32 && a.S > 288) return launch_fwd_wide(a, s);
-    }
     return tight ? launch_fwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_fwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
 
 template <int NT, bool CAUSAL>
 int32_t launch_bwd(const MhaArgs& a, hipStream_t s) {
     const bool tight = a.S > (NT - 2) * 16;
-    static const int variant = attn_env("VIPANT_ATTN_BWD", 3);
-    if constexpr (NT == 20 && !CAUSAL) {
-        // VIPANT_ATTN_BWD: 3 (default) = single pass with streamed operands (round 4), 1 = single pass with resident images
-        // (round 3), 2 = the two passes of round 2
-        if (variant == 4 && a.S > 288) return launch_bwd_wide(a, s);       // 32x32x16 MFMAs (attention_wide.hip)
-        if (variant == 3 || variant == 4) return launch_bwd1s<NT>(a, s);
-        if (variant == 1) return launch_bwd1<NT>(a, s);
-    }
-    if (NT >= 8 && attn_waves() == 8)
+    if constexpr (NT == 20 && !CAUSAL) return launch_bwd1s<NT>(a, s);       // single pass, streamed operands
+    if (NT >= 8)
         return tight ? launch_bwd_nw<NT, CAUSAL, 8, 2>(a, s) : launch_bwd_nw<NT, CAUSAL, 8, NT>(a, s);
     return tight ? launch_bwd_nw<NT, CAUSAL, 4, (NT < 2 ? NT : 2)>(a, s) : launch_bwd_nw<NT, CAUSAL, 4, NT>(a, s);
 }
 
 template <bool CAUSAL, bool BWD>
 int32_t dispatch(const MhaArgs& a, hipStream_t s) {
-    static const bool force_stream = getenv("VIPANT_ATTN_STREAM") && atoi(getenv("VIPANT_ATTN_STREAM")) == 1;   // tests / timing
-    if (force_stream) return launch_stream<CAUSAL, BWD>(a, s);
 #define VIPANT_MHA_CASE(NT) \
     if (a.S <= NT * 16) return BWD ? launch_bwd<NT, CAUSAL>(a, s) : launch_fwd<NT, CAUSAL>(a, s);
     VIPANT_MHA_CASE(2) VIPANT_MHA_CASE(4) VIPANT_MHA_CASE(6) VIPANT_MHA_CASE(10) VIPANT_MHA_CASE(14)
@@ -1703,8 +1307,7 @@ int32_t check(const void* qkv, int64_t batch, int64_t S, int64_t H) {
 extern "C" int32_t vipant_mha_fwd(const uint16_t* qkv, uint16_t* out, float* lse, int64_t batch, int64_t S, int64_t H,
                                   int32_t causal, void* stream) {
     if (int32_t e = check(qkv, batch, S, H)) return e;
-    static const int throttle = attn_env("VIPANT_ATTN_DMA_THROTTLE", 0);       // wide forward: image pieces in flight per wave (0 = all)
-    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, throttle};
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
     return causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream);
 }
 
@@ -1712,9 +1315,8 @@ extern "C" int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, cons
                                   float* delta, uint16_t* dqkv, int64_t batch, int64_t S, int64_t H, int32_t causal,
                                   void* stream) {
     if (int32_t e = check(qkv, batch, S, H)) return e;
-    static const int stagger = attn_env("VIPANT_ATTN_STAGGER", 0);
     MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv,
-              (int)batch, (int)S, (int)H, stagger};
+              (int)batch, (int)S, (int)H, 0};
     return causal ? dispatch<true, true>(a, (hipStream_t)stream) : dispatch<false, true>(a, (hipStream_t)stream);
 }
 

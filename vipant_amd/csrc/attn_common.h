@@ -1,5 +1,5 @@
-// What the attention translation units share (attention.hip: the 16x16x32 kernels and the dispatch; attention_wide.hip: the
-// 32x32x16 kernels of round 4): the argument block, the softmax constants and the wave-uniform buffer descriptor.
+// Helpers of the attention kernels (attention.hip): the argument block, the softmax constants, the wave-uniform buffer descriptor
+// and the inline-asm LDS-DMA pieces.
 #pragma once
 #include <stdlib.h>
 
@@ -41,10 +41,5 @@ __device__ __forceinline__ void lds_dma4_asm(__amdgpu_buffer_rsrc_t rs, const vo
 }
 
 #endif
-
-// attention_wide.hip: forward on v_mfma_f32_32x32x16_bf16 for 288 < S <= 320, no mask (the audio tower's shape)
-int32_t launch_fwd_wide(const MhaArgs& a, hipStream_t s);
-// ... and the single-pass backward on the same MFMA shape (streamed operands, as mha_bwd1s_kernel of attention.hip)
-int32_t launch_bwd_wide(const MhaArgs& a, hipStream_t s);
 
 }  // namespace vipant_attn

@@ -54,24 +54,38 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // process: bit d of the launcher's mask = done on device d (one process per GPU is how the package runs, but nothing here may
 // break the day one process drives two).  Races between host threads are benign: the set-up is idempotent.
 struct DeviceOnce { uint64_t mask[2] = {0, 0}; };
-static inline bool first_on_device(DeviceOnce& o) {
+// true until done_on_device() has been called for the current device: the caller runs its set-up and marks it done only when every
+// step succeeded (a failed hipFuncSetAttribute returns through VIPANT_HIP_TRY before the mark, so the next call tries again instead
+// of launching a kernel whose LDS opt-in never happened)
+static inline bool first_on_device(const DeviceOnce& o) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return true;
-    uint64_t& m = o.mask[(dev >> 6) & 1];
-    const uint64_t bit = 1ull << (dev & 63);
-    if (m & bit) return false;
-    m |= bit;
-    return true;
+    return !(o.mask[(dev >> 6) & 1] & (1ull << (dev & 63)));
 }
-// the same for a launcher whose LDS request grows with the problem: true when `bytes` exceeds what this device was set up for
+static inline void done_on_device(DeviceOnce& o) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) o.mask[(dev >> 6) & 1] |= 1ull << (dev & 63);
+}
+// the same for a launcher whose LDS request grows with the problem: true when `bytes` exceeds what this device was set up for;
+// raised_on_device() records the new value after the set-up succeeded
 struct DeviceMax { int v[128] = {}; };
-static inline bool raise_on_device(DeviceMax& o, int bytes) {
+static inline bool raise_on_device(const DeviceMax& o, int bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return true;
-    int& cur = o.v[dev & 127];
-    if (bytes <= cur) return false;
-    cur = bytes;
-    return true;
+    return bytes > o.v[dev & 127];
+}
+static inline void raised_on_device(DeviceMax& o, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && bytes > o.v[dev & 127]) o.v[dev & 127] = bytes;
+}
+// CUs of the current device (one persistent workgroup per CU), queried once per device
+static inline int device_cus() {
+    static int cus[128] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 127];
+    if (c <= 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+    return c > 0 ? c : 256;
 }
 
 // ---- ticket walk of the persistent kernels ------------------------------------------------------

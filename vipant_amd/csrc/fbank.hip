@@ -215,6 +215,7 @@ int32_t launch_fbank(const FbankArgs& a, int64_t b, hipStream_t s) {
     const size_t lds = ((size_t)4 * 2 * NFFT + NFFT / 2) * sizeof(float2) + (size_t)2 * NFFT * sizeof(float);
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)fbank_kernel<NFFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done_on_device(once);
     }
     hipLaunchKernelGGL(fbank_kernel<NFFT>, dim3((unsigned)((a.T + 8 * FPW - 1) / (8 * FPW)), (unsigned)b), dim3(256), lds, s, a);
     VIPANT_LAUNCH_CHECK();

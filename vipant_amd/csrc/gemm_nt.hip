@@ -33,6 +33,10 @@ struct GemmNT {
     // queue instead of the static stride; NULL: static walk
     uint32_t* tk = nullptr;
     uint32_t* tk_other = nullptr;      // the stream's other counter set: zeroed by this launch for the next one
+    // few-rows kernel, vipant_gemm_nt_heads only: operands carried as bf16 PAIRS x = hi + lo (two planes, the lo plane `a_lo` / `c_lo`
+    // elements behind the hi plane; 0: a single bf16 plane).  A pair in A doubles the K range (both planes against the same B rows);
+    // a pair in C keeps 16 of the accumulator's 24 mantissa bits.
+    int64_t a_lo = 0, c_lo = 0;
 };
 
 template <int EPI>
@@ -910,6 +914,7 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        done_on_device(once);
     }
     GemmNT p = p_in;
     const int64_t ntm = ceil_div(p.M, BM), ntn = ceil_div(p.N, BN);
@@ -952,6 +957,7 @@ int32_t launch_persistent(const GemmNT& p, hipStream_t stream) {
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        done_on_device(once);
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int64_t grid = tiles < 256 ? (tiles + 7) / 8 * 8 : 256;
@@ -966,6 +972,7 @@ int32_t launch(const GemmNT& p, hipStream_t stream) {
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        done_on_device(once);
     }
     const int64_t tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3((unsigned)tiles), dim3(512), 2 * STAGE_BYTES, stream, p);
@@ -983,7 +990,7 @@ int32_t launch(const GemmNT& p, hipStream_t stream) {
 // their partial tiles through LDS; wave w then owns rows 16 w .. 16 w + 15 of the tile for the epilogue (4 consecutive columns of
 // one row per lane, as everywhere in this file).
 constexpr int SK_KB = 6;          // K-steps (of 32) a wave has in flight
-template <int EPI, int NW>       // NW waves share K.  Four: eight were tried for K = 3072 and are slower (34 against 30 us at M = 512)
+template <int EPI, int NW, bool PAIR = false>     // NW waves share K.  Four: eight were tried for K = 3072 and are slower (34 against 30 us at M = 512)
 __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* part = (f32x4*)smem;                           // [NW waves][16 tiles][64 lanes]
@@ -1006,14 +1013,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nks = p.K / 32;
+    const int nk1 = p.K / 32;
+    const int nks = (PAIR && p.a_lo != 0) ? 2 * nk1 : nk1;        // a pair in A: K-steps nk1 .. 2 nk1 - 1 take the lo plane
     for (int s0 = wave * SK_KB; s0 < nks; s0 += NW * SK_KB) {
         bf16x8 af[SK_KB][4], bf[SK_KB][4];
 #pragma unroll
         for (int t = 0; t < SK_KB; ++t) {
-            const int k = (s0 + t < nks ? s0 + t : nks - 1) * 32;
+            const int st = s0 + t < nks ? s0 + t : nks - 1;
+            const int k = (PAIR && st >= nk1 ? st - nk1 : st) * 32;
+            const int64_t ka = PAIR && st >= nk1 ? p.a_lo + k : (int64_t)k;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { af[t][i] = *(const bf16x8*)(ap[i] + k); bf[t][i] = *(const bf16x8*)(bp[i] + k); }
+            for (int i = 0; i < 4; ++i) { af[t][i] = *(const bf16x8*)(ap[i] + ka); bf[t][i] = *(const bf16x8*)(bp[i] + k); }
         }
         __builtin_amdgcn_sched_barrier(0);     // all of the batch's loads issued before the first MFMA waits for one
 #pragma unroll
@@ -1044,7 +1054,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
         const int64_t o = z * p.stride_c + (int64_t)m * p.ldc + n4;
         if (EPI != VIPANT_EPI_DQUICKGELU_D8 && p.bias != nullptr) v += *(const f32x4*)(p.bias + z * p.stride_bias + n4);
         if (EPI == VIPANT_EPI_BF16) {
-            *(bf16x4*)((bf16_t*)p.C + o) = f32x4_to_bf16x4(v);
+            const bf16x4 hi = f32x4_to_bf16x4(v);
+            *(bf16x4*)((bf16_t*)p.C + o) = hi;
+            if (PAIR && p.c_lo != 0) {
+                f32x4 rest;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rest[e] = v[e] - (float)hi[e];
+                *(bf16x4*)((bf16_t*)p.C + p.c_lo + o) = f32x4_to_bf16x4(rest);
+            }
         } else if (EPI == VIPANT_EPI_F32) {
             *(f32x4*)((float*)p.C + o) = v;
         } else if (EPI == VIPANT_EPI_RESIDUAL_F32) {
@@ -1072,15 +1089,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(GemmNT p) {
     }
 }
 
-template <int EPI, int NW>
+template <int EPI, int NW, bool PAIR = false>
 int32_t launch_skinny_nw(const GemmNT& p, hipStream_t stream, int nb = 1) {
     constexpr int lds = NW * 16 * 64 * 16;
     static DeviceOnce once;
     if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI, NW, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done_on_device(once);
     }
     const unsigned grid = (unsigned)(((p.M + 63) / 64) * ((p.N + 63) / 64));
-    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW>), dim3(grid, (unsigned)nb), dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, NW, PAIR>), dim3(grid, (unsigned)nb), dim3(NW * 64), lds, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -1164,9 +1182,9 @@ extern "C" int32_t vipant_gemm_nt(const uint16_t* A, int64_t lda, const uint16_t
 // H independent small products in one launch of the few-rows kernel: the per-head contractions of the folded last block
 // (csrc/readout_ctx.hip) -- a head's 64 columns of the `batch` read-out rows against the head's block of a weight matrix -- without
 // materialising the block-sparse [batch * H, D] operand (vipant_head_expand) or computing its zeros.
-extern "C" int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, const uint16_t* B, int64_t ldb, int64_t stride_b,
-                                        uint16_t* C, int64_t ldc, int64_t stride_c, const float* bias, int64_t stride_bias, int64_t M,
-                                        int64_t N, int64_t K, int64_t H, void* stream) {
+extern "C" int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t stride_a, int64_t a_lo, const uint16_t* B, int64_t ldb,
+                                        int64_t stride_b, uint16_t* C, int64_t ldc, int64_t stride_c, int64_t c_lo, const float* bias,
+                                        int64_t stride_bias, int64_t M, int64_t N, int64_t K, int64_t H, void* stream) {
     VIPANT_REQUIRE(M > 0 && N > 0 && K > 0 && H > 0 && H < 65536 && K % 64 == 0 && N % 4 == 0, VIPANT_EBADSHAPE,
                    "gemm_nt_heads: bad shape M=%ld N=%ld K=%ld H=%ld (K %% 64, N %% 4)", (long)M, (long)N, (long)K, (long)H);
     VIPANT_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && stride_a % 8 == 0 &&
@@ -1174,8 +1192,11 @@ extern "C" int32_t vipant_gemm_nt_heads(const uint16_t* A, int64_t lda, int64_t 
                    "gemm_nt_heads: leading dimensions / head strides must keep 16-byte (operands), 8-byte (C) and 16-byte (bias) alignment");
     VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0) && ((uintptr_t)bias % 16 == 0),
                    VIPANT_EALIGN, "gemm_nt_heads: operands must be 16-byte aligned");
+    VIPANT_REQUIRE(a_lo % 8 == 0 && c_lo % 4 == 0 && a_lo >= 0 && c_lo >= 0, VIPANT_EALIGN, "gemm_nt_heads: the lo planes must keep the operands' alignment");
     GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, nullptr, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, 0, nullptr, nullptr, 0, nullptr,
              stride_a, stride_b, stride_c, stride_bias};
+    p.a_lo = a_lo; p.c_lo = c_lo;
+    if (a_lo != 0 || c_lo != 0) return launch_skinny_nw<VIPANT_EPI_BF16, 4, true>(p, (hipStream_t)stream, (int)H);
     return launch_skinny_nw<VIPANT_EPI_BF16, 4>(p, (hipStream_t)stream, (int)H);
 }
 

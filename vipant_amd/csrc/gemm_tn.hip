@@ -534,6 +534,7 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            PP_LDS_BYTES));
         variant = getenv("VIPANT_GEMM_VARIANT") ? atoi(getenv("VIPANT_GEMM_VARIANT")) : 0;     // bit 16: the two-stage kernel
+        done_on_device(once);
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
@@ -594,6 +595,7 @@ extern "C" int32_t vipant_gemm_tn_pair(const uint16_t* A0, const uint16_t* B0, f
     static DeviceOnce once;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn_pp_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        done_on_device(once);
     }
     hipStream_t s = (hipStream_t)stream;
     const int direct = splits == 1 ? 1 : 0;

@@ -554,6 +554,7 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        done_on_device(once);
     }
     const int K = (int)(3 * E);
     const unsigned tiles = (unsigned)(ceil_div(B, BM) * ceil_div(B, BN));

@@ -54,7 +54,8 @@ __device__ __forceinline__ void widen(const RawRow<EPL>& r, float (&x)[EPL]) {
 template <int EPL>
 __device__ __forceinline__ void load_row(const bf16_t* row, int lane, float (&x)[EPL]) { widen<EPL>(load_raw<EPL>(row, lane), x); }
 __device__ __forceinline__ int key_limit(const int64_t* idx, int item, int S, int causal) {
-    if (!causal || idx == nullptr) return S;
+    if (!causal) return S;
+    if (idx == nullptr) return 1;          // causal, read-out row 0: one key (as csrc/readout_rows.hip's row_index gives)
     const int64_t v = idx[item];
     return (int)(v < 0 ? 0 : (v >= S ? S - 1 : v)) + 1;
 }
@@ -121,17 +122,21 @@ __device__ __forceinline__ void fill_images(char* imgs, __amdgpu_buffer_rsrc_t r
 // (A) of both kernels: [32 tokens] x [16 heads] dot products over D: wave w takes token tile w & 1 and the K half w >> 1, the two
 // halves are added by the reader.  part: [2 halves][16 heads][32 tokens] fp32; bq: the heads' vectors as B fragments, this wave's K half
 // (a register array indexed by the wave's number would live in scratch memory).
-template <int NI>
-__device__ __forceinline__ void dots_round(const char* imgs, const ImgLane& a, const bf16x8 (&bq)[NI], float* part, int wave, int r,
-                                           int g) {
+// PAIR: the heads' vectors are bf16 pairs (hi + lo, round 5): the lo plane's fragments take a second MFMA against the same token rows.
+template <int NI, bool PAIR>
+__device__ __forceinline__ void dots_round(const char* imgs, const ImgLane& a, const bf16x8 (&bq)[NI], const bf16x8 (&bl)[PAIR ? NI : 1],
+                                           float* part, int wave, int r, int g) {
     const int tile = wave & 1, kh = wave >> 1;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ii = 0; ii < NI / 2; ++ii) {
         const int img = kh * (NI / 2) + ii;
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(imgs + img * 4096, a, tile, ds), bq[2 * ii + ds], acc, 0, 0, 0);
+        for (int ds = 0; ds < 2; ++ds) {
+            const bf16x8 fr = img_row_frag(imgs + img * 4096, a, tile, ds);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, bq[2 * ii + ds], acc, 0, 0, 0);
+            if (PAIR) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, bl[2 * ii + ds], acc, 0, 0, 0);
+        }
     }
     *(f32x4*)(part + (kh * 16 + r) * 32 + 16 * tile + 4 * g) = acc;
 }
@@ -141,10 +146,12 @@ __device__ __forceinline__ void dots_round(const char* imgs, const ImgLane& a, c
 // on the matrix pipe; (B) wave w owns heads HPW w ..: one lane per token takes the round's maximum, the rescale factor and the
 // exponentials, left in LDS as bf16 P[head][token]; (C) ctx^T[columns x heads] += h1^T[columns x tokens] . P^T[tokens x heads], wave w
 // owning columns D / 4 * w ..: transposed fragments of the images.  Raw scores wait in LDS until maximum and sum are final.
-template <int NI, int HPW, int MINB>
+// PAIR (round 5): qk and ctx are bf16 pairs, x = hi + lo in two planes `lo` elements apart -- these [batch * H, D] tensors carried a bf16
+// rounding per (item, head) that the full block does not have (profiles/r5_parity_observed.jsonl); the kernel is HBM-bound on h1.
+template <int NI, int HPW, int MINB, bool PAIR>
 __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ h1,
                                                                  const int64_t* __restrict__ idx, bf16_t* __restrict__ ctx,
-                                                                 float* __restrict__ probs, int S, int causal) {
+                                                                 float* __restrict__ probs, int S, int causal, int64_t lo) {
     constexpr int D = NI * 64, NH = 4 * HPW, IPW = NI / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* imgs = smem;                                          // NI x 4 KiB
@@ -160,13 +167,14 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* _
     const bf16_t* rows = h1 + (int64_t)item * S * D;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(rows, (uint32_t)S * D * 2);
     const ImgLane a = img_lane(lane);
-    bf16x8 bq[NI];
+    bf16x8 bq[NI], bl[PAIR ? NI : 1];
     {
         const bf16_t* qrow = qk + ((int64_t)item * NH + (r < NH ? r : 0)) * D + (wave >> 1) * (D / 2) + 8 * g;
 #pragma unroll
         for (int s = 0; s < NI; ++s) {
             bq[s] = *(const bf16x8*)(qrow + 32 * s);
-            if (r >= NH) bq[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (PAIR) bl[s] = *(const bf16x8*)(qrow + lo + 32 * s);
+            if (r >= NH) { bq[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; if (PAIR) bl[s] = bq[s]; }
         }
     }
     for (int i = threadIdx.x; i < 16 * 32 / 2; i += 256) ((uint32_t*)pbuf)[i] = 0u;        // heads NH .. 15 stay zero
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* _
     for (int j0 = 0; j0 < nkeys; j0 += 32) {
         fill_images<NI>(imgs, rs, j0, wave, lane);
         __syncthreads();
-        dots_round<NI>(imgs, a, bq, part, wave, r, g);                                        // (A)
+        dots_round<NI, PAIR>(imgs, a, bq, bl, part, wave, r, g);                              // (A)
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < HPW; ++h) {                                                       // (B)
@@ -226,7 +234,14 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* _
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = f32x4_to_bf16x4(acc[ii][dt] * iv);
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = acc[ii][dt] * iv;
+                const bf16x4 hi = f32x4_to_bf16x4(v);
+                *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = hi;
+                if (PAIR)
+                    *(bf16x4*)(orow + lo + 64 * (IPW * wave + ii) + 16 * dt) =
+                        f32x4_to_bf16x4(f32x4{v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]});
+            }
     }
 #pragma unroll
     for (int h = 0; h < HPW; ++h) {
@@ -242,11 +257,18 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_fwd_kernel(const bf16_t* _
 // += h1^T . dS^T from transposed image fragments, wave w owning columns D / 4 * w ..; (D) dh1 of the round as ONE product per 16 tokens
 // x 16 columns: (dh1 tile)^T = [dctx | qk]^T [16 columns x 32] . [p | ds]^T [32 x 16 tokens] -- the left operand, for the wave's D / 4
 // columns, is resident in registers (built once per item through the image area), the result leaves as 16-byte stores.
-template <int NI, int HPW, int MINB>
+// PAIR (round 5): qk, ctx and dqk are bf16 pairs (planes `lo` elements apart); dctx is a single bf16 plane.  ctx enters delta = dctx . ctx
+// with both planes, dqk leaves as a pair (its consumer, dq = W_k dqk, takes both planes).  dctx = W_v^T do is a linear image of `do`,
+// which is bf16 itself, and enters dp = dctx . h1 and delta with the SAME rounded value, so its rounding is a 2^-9 relative
+// perturbation of `do` that the difference dp - delta does not amplify; a second plane for it would cost the 48 registers of a second
+// resident fragment set (the kernel spills at 256).  The resident [dctx | qk]^T operand of (D) keeps qk's hi plane: dh1 leaves as one
+// bf16 per element anyway.
+template <int NI, int HPW, int MINB, bool PAIR>
 __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ dctx,
                                                                  const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ h1,
                                                                  const int64_t* __restrict__ idx, const float* __restrict__ probs,
-                                                                 bf16_t* __restrict__ dh1, bf16_t* __restrict__ dqk, int S, int causal) {
+                                                                 bf16_t* __restrict__ dh1, bf16_t* __restrict__ dqk, int S, int causal,
+                                                                 int64_t lo) {
     constexpr int D = NI * 64, NH = 4 * HPW, IPW = NI / 4, CT = NI, EPL = NI;     // CT: 16-column tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* imgs = smem;                                          // NI x 4 KiB (first: [D][32] bf16, the item's [dctx | qk]^T)
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
             dcq[n * 32 + 8 * ((2 + (hh >> 3)) ^ sw) + (hh & 7)] = vq[e];
         }
     }
-    bf16x8 bq[NI];
+    bf16x8 bq[NI], bl[1];
     {
         const bf16_t* qrow = dctx + ((int64_t)item * NH + (r < NH ? r : 0)) * D + (wave >> 1) * (D / 2) + 8 * g;
 #pragma unroll
@@ -291,6 +313,12 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
         float dc[EPL], c[EPL];
         load_row<EPL>(dctx + (head0 + h) * D, lane, dc);
         load_row<EPL>(ctx + (head0 + h) * D, lane, c);
+        if (PAIR) {
+            float cl[EPL];
+            load_row<EPL>(ctx + lo + (head0 + h) * D, lane, cl);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) c[e] += cl[e];
+        }
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) d = __builtin_fmaf(dc[e], c[e], d);
@@ -318,7 +346,7 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
         for (int h = 0; h < HPW; ++h) pj[h] = (lane < 32 && j0 + lane < nkeys) ? probs[(head0 + h) * S + j0 + lane] : 0.f;
         if (live) fill_images<NI>(imgs, rs, j0, wave, lane);
         __syncthreads();
-        if (live) dots_round<NI>(imgs, a, bq, part, wave, r, g);                                // (A)
+        if (live) dots_round<NI, false>(imgs, a, bq, bl, part, wave, r, g);                     // (A)
         __syncthreads();
         if (lane < 32) {                                                                      // (B)
             const int sw = (lane >> 2) & 3;
@@ -361,7 +389,14 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
 #pragma unroll
         for (int ii = 0; ii < IPW; ++ii)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = f32x4_to_bf16x4(acc[ii][dt]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = acc[ii][dt];
+                const bf16x4 hi = f32x4_to_bf16x4(v);
+                *(bf16x4*)(orow + 64 * (IPW * wave + ii) + 16 * dt) = hi;
+                if (PAIR)
+                    *(bf16x4*)(orow + lo + 64 * (IPW * wave + ii) + 16 * dt) =
+                        f32x4_to_bf16x4(f32x4{v[0] - (float)hi[0], v[1] - (float)hi[1], v[2] - (float)hi[2], v[3] - (float)hi[3]});
+            }
     }
 }
 
@@ -399,29 +434,32 @@ int32_t check_ctx(int64_t batch, int64_t S, int64_t H) {
     return VIPANT_OK;
 }
 
-template <int EPL, int HPW, int MINB>
+template <int EPL, int HPW, int MINB, bool PAIR>
 int32_t launch_fwd(const bf16_t* qk, const bf16_t* h1, const int64_t* idx, bf16_t* ctx, float* probs, int batch, int S, int causal,
-                   hipStream_t st) {
+                   int64_t lo, hipStream_t st) {
     const int lds = EPL * 4096 + 4096 + 1024 + 64 + 4 * HPW * ((S + 31) & ~31) * (int)sizeof(float);
     static DeviceMax most;
     if (raise_on_device(most, lds)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_fwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_fwd_kernel<EPL, HPW, MINB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        raised_on_device(most, lds);
     }
-    hipLaunchKernelGGL((rows_ctx_fwd_kernel<EPL, HPW, MINB>), dim3((unsigned)batch), dim3(256), lds, st, qk, h1, idx, ctx, probs, S, causal);
+    hipLaunchKernelGGL((rows_ctx_fwd_kernel<EPL, HPW, MINB, PAIR>), dim3((unsigned)batch), dim3(256), lds, st, qk, h1, idx, ctx, probs, S, causal,
+                       lo);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
-template <int EPL, int HPW, int MINB>
+template <int EPL, int HPW, int MINB, bool PAIR>
 int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, const bf16_t* h1, const int64_t* idx, const float* probs,
-                   bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, hipStream_t st) {
+                   bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, int64_t lo, hipStream_t st) {
     constexpr int lds = EPL * 4096 + 4096 + 1024 + 2048;
     static DeviceOnce once;
     if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_bwd_kernel<EPL, HPW, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)rows_ctx_bwd_kernel<EPL, HPW, MINB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done_on_device(once);
     }
-    hipLaunchKernelGGL((rows_ctx_bwd_kernel<EPL, HPW, MINB>), dim3((unsigned)batch), dim3(256), lds, st, qk, dctx, ctx, h1, idx, probs, dh1,
-                       dqk, S, causal);
+    hipLaunchKernelGGL((rows_ctx_bwd_kernel<EPL, HPW, MINB, PAIR>), dim3((unsigned)batch), dim3(256), lds, st, qk, dctx, ctx, h1, idx, probs, dh1,
+                       dqk, S, causal, lo);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -429,20 +467,27 @@ int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, cons
 }  // namespace
 
 extern "C" int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_t* idx, uint16_t* ctx, float* probs,
-                                       int64_t batch, int64_t S, int64_t H, int32_t causal, void* stream) {
+                                       int64_t batch, int64_t S, int64_t H, int32_t causal, int32_t pair, void* stream) {
     if (int32_t e = check_ctx(batch, S, H)) return e;
     VIPANT_REQUIRE(qk != nullptr && h1 != nullptr && ctx != nullptr && probs != nullptr, VIPANT_EBADSHAPE, "rows_ctx_fwd: null operand");
     VIPANT_REQUIRE((uintptr_t)qk % 16 == 0 && (uintptr_t)h1 % 16 == 0 && (uintptr_t)ctx % 16 == 0, VIPANT_EALIGN,
                    "rows_ctx_fwd: operands must be 16-byte aligned");
     const bf16_t *a = (const bf16_t*)qk, *b = (const bf16_t*)h1;
-    if (H == 12) return launch_fwd<12, 3, 2>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, (hipStream_t)stream);
-    if (H == 16) return launch_fwd<16, 4, 1>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, (hipStream_t)stream);
-    return launch_fwd<8, 2, 2>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, (hipStream_t)stream);
+    const int64_t lo = batch * H * H * 64;          // the lo planes of qk / ctx: [2][batch * H][D]
+    hipStream_t st = (hipStream_t)stream;
+    if (pair) {
+        if (H == 12) return launch_fwd<12, 3, 2, true>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, lo, st);
+        if (H == 16) return launch_fwd<16, 4, 1, true>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, lo, st);
+        return launch_fwd<8, 2, 2, true>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, lo, st);
+    }
+    if (H == 12) return launch_fwd<12, 3, 2, false>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, 0, st);
+    if (H == 16) return launch_fwd<16, 4, 1, false>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, 0, st);
+    return launch_fwd<8, 2, 2, false>(a, b, idx, (bf16_t*)ctx, probs, (int)batch, (int)S, causal, 0, st);
 }
 
 extern "C" int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1,
                                        const int64_t* idx, const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S,
-                                       int64_t H, int32_t causal, void* stream) {
+                                       int64_t H, int32_t causal, int32_t pair, void* stream) {
     if (int32_t e = check_ctx(batch, S, H)) return e;
     VIPANT_REQUIRE(qk != nullptr && dctx != nullptr && ctx != nullptr && h1 != nullptr && probs != nullptr && dh1 != nullptr && dqk != nullptr,
                    VIPANT_EBADSHAPE, "rows_ctx_bwd: null operand");
@@ -450,9 +495,15 @@ extern "C" int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx,
                    (uintptr_t)dh1 % 16 == 0 && (uintptr_t)dqk % 16 == 0, VIPANT_EALIGN, "rows_ctx_bwd: operands must be 16-byte aligned");
     const bf16_t *a = (const bf16_t*)qk, *b = (const bf16_t*)dctx, *c = (const bf16_t*)ctx, *d = (const bf16_t*)h1;
     hipStream_t st = (hipStream_t)stream;
-    if (H == 12) return launch_bwd<12, 3, 2>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, st);
-    if (H == 16) return launch_bwd<16, 4, 1>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, st);
-    return launch_bwd<8, 2, 2>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, st);
+    const int64_t lo = batch * H * H * 64;
+    if (pair) {
+        if (H == 12) return launch_bwd<12, 3, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
+        if (H == 16) return launch_bwd<16, 4, 1, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
+        return launch_bwd<8, 2, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
+    }
+    if (H == 12) return launch_bwd<12, 3, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
+    if (H == 16) return launch_bwd<16, 4, 1, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
+    return launch_bwd<8, 2, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
 }
 
 extern "C" int32_t vipant_head_expand(const uint16_t* rows, uint16_t* out, int64_t n, int64_t H, void* stream) {

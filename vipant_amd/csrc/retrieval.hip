@@ -163,6 +163,7 @@ extern "C" int32_t vipant_retrieval_ranks(const float* x1, const float* x2, cons
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)ret_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)ret_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        done_on_device(once);
     }
     auto blocks = [](int64_t n) { const int64_t b = ceil_div(n, 256); return (unsigned)(b > 4096 ? 4096 : b); };
     hipLaunchKernelGGL(ret_prep_kernel, dim3(blocks(N1 * E)), dim3(256), 0, s, x1, w.x1cat, N1 * E, (int)E, 0);

@@ -459,23 +459,26 @@ LAST_BLOCK_CTX = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0"
 def heads_to_wide(rows: torch.Tensor, w_t_cols: torch.Tensor, out: torch.Tensor, H: int) -> torch.Tensor:
     """out[(i, h), :] = rows[i, 64 h : 64 h + 64] . W_h, all heads in one launch (vipant_gemm_nt_heads): rows bf16 [n, D]; w_t_cols:
     the column block [:, c0 : c0 + D] of a TRANSPOSED weight matrix (bf16 [D, ld], a view: W_h^T is its columns 64 h ..); out bf16
-    [n * H, D]."""
+    [n * H, D], or [2, n * H, D]: the result as a bf16 pair (hi plane, lo plane)."""
     n, D = rows.shape
-    assert D == 64 * H and tuple(out.shape) == (n * H, D) and w_t_cols.shape == (D, D) and w_t_cols.stride(1) == 1
-    call("vipant_gemm_nt_heads", rows.data_ptr(), D, 64, w_t_cols.data_ptr(), w_t_cols.stride(0), 64, out.data_ptr(), H * D, D, None, 0,
-         n, D, 64, H, _stream())
+    pair = out.dim() == 3
+    assert D == 64 * H and tuple(out.shape[-2:]) == (n * H, D) and w_t_cols.shape == (D, D) and w_t_cols.stride(1) == 1 and out.is_contiguous()
+    call("vipant_gemm_nt_heads", rows.data_ptr(), D, 64, 0, w_t_cols.data_ptr(), w_t_cols.stride(0), 64, out.data_ptr(), H * D, D,
+         n * H * D if pair else 0, None, 0, n, D, 64, H, _stream())
     return out
 
 
 def wide_to_heads(wide: torch.Tensor, w_rows: torch.Tensor, H: int, bias=None) -> torch.Tensor:
-    """out[i, 64 h : 64 h + 64] = wide[(i, h), :] . W_h^T (+ bias of those columns), all heads in one launch: wide bf16 [n * H, D];
-    w_rows: the row block [r0 : r0 + D] of a weight matrix (bf16 [D, D], contiguous: W_h is its rows 64 h ..); out bf16 [n, D]."""
-    nH, D = wide.shape
+    """out[i, 64 h : 64 h + 64] = wide[(i, h), :] . W_h^T (+ bias of those columns), all heads in one launch: wide bf16 [n * H, D]
+    (or a bf16 pair [2, n * H, D]: both planes enter the product); w_rows: the row block [r0 : r0 + D] of a weight matrix (bf16
+    [D, D], contiguous: W_h is its rows 64 h ..); out bf16 [n, D]."""
+    pair = wide.dim() == 3
+    nH, D = wide.shape[-2:]
     n = nH // H
     assert D == 64 * H and nH % H == 0 and wide.is_contiguous() and w_rows.shape == (D, D) and w_rows.is_contiguous()
     out = torch.empty((n, D), dtype=BF16, device=wide.device)
-    call("vipant_gemm_nt_heads", wide.data_ptr(), H * D, D, w_rows.data_ptr(), D, 64 * D, out.data_ptr(), D, 64, _ptr(bias), 64,
-         n, 64, D, H, _stream())
+    call("vipant_gemm_nt_heads", wide.data_ptr(), H * D, D, nH * D if pair else 0, w_rows.data_ptr(), D, 64 * D, out.data_ptr(), D, 64, 0,
+         _ptr(bias), 64, n, 64, D, H, _stream())
     return out
 
 
@@ -606,10 +609,11 @@ class BackboneFn(torch.autograd.Function):
                     # of the softmax), the value projection behind the weighted sum (o_h = W_v,h sum_j p_j h1_j + b_v,h): two
                     # per-head contractions on `batch` rows and one pass over h1 instead of K, V of every token
                     wk_t = (wqkv_t if train else cached_bf16(wqkv, transpose_only=True))[:, D:2 * D]
-                    qkv = torch.empty((2, batch * H, D), dtype=BF16, device=dev)            # [0]: qk, [1]: the heads' contexts
+                    # qk and the heads' contexts travel as bf16 PAIRS (hi + lo planes, round 5): [0]: qk, [1]: contexts
+                    qkv = torch.empty((2, 2, batch * H, D), dtype=BF16, device=dev)
                     heads_to_wide(q_r, wk_t, qkv[0], H)
                     call("vipant_rows_ctx_fwd", qkv[0].data_ptr(), h1.data_ptr(), _ptr(ridx), qkv[1].data_ptr(), probs.data_ptr(),
-                         batch, S, H, int(causal), st)
+                         batch, S, H, int(causal), 1, st)
                     o_r = wide_to_heads(qkv[1], wqkv_b[2 * D:], H, bias=bqkv[2 * D:])
                 else:
                     if qkv is None:
@@ -758,14 +762,16 @@ class BackboneFn(torch.autograd.Function):
                     wqkv_b_last = ctx.wqkv_b_last
                     # qkv = [qk | contexts] of the forward.  dctx_h = W_v,h^T do_h; the kernel gives dh of every token and dqk;
                     # dq_h = W_k,h dqk_h; d W_v = do (x) ctx, d W_k = q (x) dqk per head (block-sparse operands), d b_k = 0
+                    # (qk, the contexts and dqk are bf16 pairs; the two weight gradients take the hi planes: their own rounding, fp32
+                    # sums over `batch * H` bf16 products, is the larger term)
                     qk, hctx = qkv[0], qkv[1]
                     dctx = heads_to_wide(do_r, wqkv_t[:, 2 * D:], torch.empty((batch * H, D), dtype=BF16, device=dev), H)
-                    gemm_tn(head_expand(do_r, H), hctx, d_wqkv[2 * D:], a_colsum=d_bqkv[2 * D:], ws_name="block_bwd")
-                    dqk = torch.empty((batch * H, D), dtype=BF16, device=dev)
+                    gemm_tn(head_expand(do_r, H), hctx[0], d_wqkv[2 * D:], a_colsum=d_bqkv[2 * D:], ws_name="block_bwd")
+                    dqk = torch.empty((2, batch * H, D), dtype=BF16, device=dev)
                     call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), _ptr(ridx),
-                         probs.data_ptr(), dh.data_ptr(), dqk.data_ptr(), batch, S, H, int(causal), st)
+                         probs.data_ptr(), dh.data_ptr(), dqk.data_ptr(), batch, S, H, int(causal), 1, st)
                     dq_r = wide_to_heads(dqk, wqkv_b_last[D:2 * D], H)
-                    gemm_tn(head_expand(q_r, H), dqk, d_wqkv[D:2 * D], ws_name="block_bwd")
+                    gemm_tn(head_expand(q_r, H), dqk[0], d_wqkv[D:2 * D], ws_name="block_bwd")
                     d_bqkv[D:2 * D].zero_()
                     del dctx, dqk
                 else:
