@@ -45,7 +45,7 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=Fa
     return (layers - 1) * full + last + 2 * P * kpatch * width + 2 * width * embed if layers > 0 else 2 * P * kpatch * width + 2 * width * embed
 
 
-PMC_FILE = "profiles/r3_pmc_traffic.json"      # (same kernel and shape this round: not re-collected)
+PMC_FILE = "profiles/r5_pmc_traffic.json"      # this round's counter passes on the shipped build (tools/round_batch.sh pmc)
 
 
 def pmc_traffic(M, N, K):
@@ -89,6 +89,9 @@ def parse():
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
                          "CLIP text tower at L=77, local negatives (run_bimodal_at.sh); extra measurement, not the headline")
     ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--comm-overlap", choices=["block", "step"], default="block",
+                    help="running.comm_overlap: replicas reduce each block's gradient bucket while the blocks below run their backward "
+                         "(block, default) or all buckets as one collective after the backward (step)")
     return ap.parse_args()
 
 
@@ -313,7 +316,7 @@ def main():
           f"model.audio.width={args.width} model.audio.encoder.layers={args.layers} "
           f"running.recompute_mlp={args.recompute_mlp} running.micro_batch={args.micro_batch} running.fp8_gemm={args.fp8} "
           + (f"running.stream_dtype={args.stream} " if args.stream else "") + f"running.last_block_rows={not args.full_last_block} " +
-          f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} "
+          f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.comm_overlap={args.comm_overlap} "
           f"running.batch_size={b} running.epochs=1000 running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 "
           f"running.synthetic_steps={args.steps + args.warmup} num_gpus={world}").split()
     cfg = compose(ov)
@@ -389,6 +392,7 @@ def main():
                                "fwd+bwd + frozen CLIP ViT-B/32 image tower fwd + InfoNCE + LARS (BASELINE.json configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",
                    "negatives": "global (all-gather)" if world > 1 else "global",
+                   "comm_overlap": args.comm_overlap if world > 1 else "none (one replica)",
                    # every feature and gradient is what the full block gives; --full-last-block computes the discarded rows too
                    "last_block": "read-out rows only (dead-row elimination: exact up to bf16 rounding order)" if lbr else "every token"},
         "loss": round(float(loss.detach()), 4),
@@ -434,6 +438,17 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out["infonce_alone"]["ms_at_B512"] = round(e0.elapsed_time(e1) / 20, 4)
+        # ... and in the form one rank of the 8-GPU step runs: all 4096 x 4096 logits for the loss, gradients for its 512 rows only
+        for _ in range(3):
+            ops.InfoNCEFn.apply(x1, x2, ls, None, Bn - 512, 512, 1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.InfoNCEFn.apply(x1, x2, ls, None, Bn - 512, 512, 1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        out["infonce_alone"]["ms_rank_strip_512_of_4096"] = round(e0.elapsed_time(e1) / 10, 4)
+        out["infonce_alone"]["workspace_mb"] = round(_ffi.query("vipant_infonce_workspace_bytes", Bn, E) / 1e6, 1)
         if world == 1 and lbr and not args.no_full_last_block_check:
             # transparency: the same build, same box, with the towers' last block evaluated on EVERY token (what the reference
             # computes before its read-out discards all rows but one) -- a short untimed-region extra, never `value`

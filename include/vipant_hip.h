@@ -158,11 +158,12 @@ int32_t vipant_mha_rows_bwd(const uint16_t* q_rows, const uint16_t* qkv, const i
  * produce and consume them, so the folded form adds no rounding the reference's attention does not have. */
 int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, const int64_t* idx, uint16_t* ctx, float* probs, int64_t batch,
                             int64_t S, int64_t H, int32_t causal, int32_t pair, void* stream);
-/* dctx bf16 [batch*H, D]: row (i, h) = W_v,h^T dout_(i,h).  dh1 bf16 [batch*S, D]: the attention's gradient for EVERY token's h1 row
- * (zeros behind a causal limit; all rows written);  dqk bf16 [batch*H, D]: gradient of qk. */
+/* dctx bf16 [batch*H, D] (a single plane also with pair != 0): row (i, h) = W_v,h^T dout_(i,h).  dh1 bf16 [batch*S, D]: the attention's
+ * gradient for EVERY token's h1 row (zeros behind a causal limit; all rows written);  dqk bf16 [batch*H, D] (a pair with pair != 0):
+ * gradient of qk;  dbk fp32 [D] or NULL: the key bias's gradient, exact zeros (a bias on the keys cannot move a softmax over keys). */
 int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1, const int64_t* idx,
-                            const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S, int64_t H, int32_t causal,
-                            int32_t pair, void* stream);
+                            const float* probs, uint16_t* dh1, uint16_t* dqk, float* dbk, int64_t batch, int64_t S, int64_t H,
+                            int32_t causal, int32_t pair, void* stream);
 /* H independent products in one launch, C_h[M, N] = A_h[M, K] . B_h[N, K]^T (+ bias_h), bf16 in and out, operand h starting
  * h * stride elements behind operand 0: the per-head contractions of the folded form (a head's 64 columns of the `batch` read-out
  * rows against that head's block of W_k / W_v, and back) without the block-sparse [batch * H, D] operand of vipant_head_expand.

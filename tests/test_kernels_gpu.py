@@ -512,12 +512,14 @@ def test_rows_ctx(ops, batch, S, H, causal, with_idx, pair):
     dh1 = torch.full((batch * S, D), 7.0, dtype=torch.bfloat16, device=DEV)
     dqk = torch.full(shape, 7.0, dtype=torch.bfloat16, device=DEV)
     ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), ip, probs.data_ptr(), dh1.data_ptr(),
-             dqk.data_ptr(), batch, S, H, int(causal), pair, st)
+             dqk.data_ptr(), None, batch, S, H, int(causal), pair, st)
     assert_close(dh1.view(batch, S, D), hd.grad, 2e-2, 2e-2 * hd.grad.abs().max().item(), "rows_ctx dh1")
-    assert_close(value(dqk).view(batch, H, D), qd.grad, 2e-2, 2e-2 * qd.grad.abs().max().item(), "rows_ctx dqk")
+    assert_close(value(dqk).view(batch, H, D), qd.grad, 2e-2, 2e-2 * max(qd.grad.abs().max().item(), 1e-3), "rows_ctx dqk")
     if pair:        # the lo plane is what the hi plane's rounding left: |lo| <= 2^-8 |hi| elementwise, and not identically zero
-        assert float((dqk[1].float().abs() - 2.0 ** -8 * dqk[0].float().abs()).max()) <= 1e-30 and float(dqk[1].float().abs().max()) > 0
-        assert float((ctx[1].float().abs() - 2.0 ** -8 * ctx[0].float().abs()).max()) <= 1e-30 and float(ctx[1].float().abs().max()) > 0
+        one_key = causal and not with_idx        # softmax over one key: the context IS that bf16 row, dqk is exactly zero
+        assert float((dqk[1].float().abs() - 2.0 ** -8 * dqk[0].float().abs()).max()) <= 1e-30
+        assert float((ctx[1].float().abs() - 2.0 ** -8 * ctx[0].float().abs()).max()) <= 1e-30
+        assert one_key or (float(dqk[1].float().abs().max()) > 0 and float(ctx[1].float().abs().max()) > 0)
     if S == 1024:
         with pytest.raises(Exception):      # one token more: refused (the caller takes the K / V form)
             ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), ip, ctx.data_ptr(), probs.data_ptr(), batch, S + 1, H, int(causal), pair, st)
@@ -820,7 +822,7 @@ def test_round4_kernels_are_repeatable_under_load(ops):
         ops.call("vipant_rows_ctx_fwd", qk.data_ptr(), h1.data_ptr(), None, ctx.data_ptr(), probs.data_ptr(), b, S, H, 0, 1, st)
         dh1 = torch.empty(b * S, D, dtype=torch.bfloat16, device=DEV); dqk = torch.empty(2, b * H, D, dtype=torch.bfloat16, device=DEV)
         ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), ctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
-                 dqk.data_ptr(), b, S, H, 0, 1, st)
+                 dqk.data_ptr(), None, b, S, H, 0, 1, st)
         few = ops.gemm_nt(rows, w[:D], torch.empty(512, D, dtype=torch.bfloat16, device=DEV), bias=bias, few_rows=True)
         res = ops.gemm_nt(rows, w[:D], torch.empty(512, D, device=DEV), bias=bias, aux=x1[:, :1].expand(512, D).contiguous(),
                           epi=ops.EPI_RESIDUAL_F32, few_rows=True)

@@ -58,7 +58,7 @@ def cfwd():
 
 def cbwd():
     ops.call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), None, probs.data_ptr(), dh1.data_ptr(),
-             dqk.data_ptr(), b, S, H, 0, PAIR, st)
+             dqk.data_ptr(), None, b, S, H, 0, PAIR, st)
 
 
 for name, fn, nbytes in (("fwd", cfwd, b * S * D * 2), ("bwd", cbwd, 2 * b * S * D * 2)):

@@ -56,7 +56,7 @@ PROTOTYPES = {
     "vipant_mha_rows_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_rows_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_rows_ctx_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
-    "vipant_rows_ctx_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
+    "vipant_rows_ctx_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
     "vipant_gemm_nt_heads": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p]),
     "vipant_head_expand": (_i32, [_p, _p, _i64, _i64, _p]),
     "vipant_head_extract": (_i32, [_p, _i32, _p, _p, _i64, _i64, _p]),

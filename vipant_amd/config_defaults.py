@@ -27,6 +27,8 @@ _running_common = {
     # activation-memory plan for batches that do not fit: towers in micro-batches under one global-batch loss,
     # and / or the MLP activations recomputed in the backward
     "micro_batch": 0, "recompute_mlp": False, "fp8_gemm": False, "stream_dtype": "fp16", "grad_stream": None, "last_block_rows": True,
+    # replicas: when a block's gradient bucket is reduced (vipant_amd/parallel.py GradSync): block | step
+    "comm_overlap": "block",
 }
 
 GROUPS = {

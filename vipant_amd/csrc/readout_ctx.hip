@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ h1,
                                                                  const int64_t* __restrict__ idx, const float* __restrict__ probs,
                                                                  bf16_t* __restrict__ dh1, bf16_t* __restrict__ dqk, int S, int causal,
-                                                                 int64_t lo) {
+                                                                 int64_t lo, float* __restrict__ dbk) {
     constexpr int D = NI * 64, NH = 4 * HPW, IPW = NI / 4, CT = NI, EPL = NI;     // CT: 16-column tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* imgs = smem;                                          // NI x 4 KiB (first: [D][32] bf16, the item's [dctx | qk]^T)
@@ -277,6 +277,10 @@ __global__ __launch_bounds__(256, MINB) void rows_ctx_bwd_kernel(const bf16_t* _
     bf16_t* pds = dsbuf + 16 * 32;                              // [32 tokens][32]: p of 16 heads | ds of 16 heads
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const int item = blockIdx.x;
+    // d b_k = 0 EXACTLY (a bias on the keys adds the same constant to every score of a query: the softmax does not see it); written
+    // here, by the first workgroup, so that the caller needs no fill launch for it
+    if (item == 0 && dbk != nullptr)
+        for (int i = threadIdx.x; i < D; i += 256) dbk[i] = 0.f;
     const int nkeys = key_limit(idx, item, S, causal);
     const int64_t head0 = (int64_t)item * NH + HPW * wave;
     const bf16_t* rows = h1 + (int64_t)item * S * D;
@@ -451,7 +455,7 @@ int32_t launch_fwd(const bf16_t* qk, const bf16_t* h1, const int64_t* idx, bf16_
 
 template <int EPL, int HPW, int MINB, bool PAIR>
 int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, const bf16_t* h1, const int64_t* idx, const float* probs,
-                   bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, int64_t lo, hipStream_t st) {
+                   bf16_t* dh1, bf16_t* dqk, int batch, int S, int causal, int64_t lo, float* dbk, hipStream_t st) {
     constexpr int lds = EPL * 4096 + 4096 + 1024 + 2048;
     static DeviceOnce once;
     if (first_on_device(once)) {
@@ -459,7 +463,7 @@ int32_t launch_bwd(const bf16_t* qk, const bf16_t* dctx, const bf16_t* ctx, cons
         done_on_device(once);
     }
     hipLaunchKernelGGL((rows_ctx_bwd_kernel<EPL, HPW, MINB, PAIR>), dim3((unsigned)batch), dim3(256), lds, st, qk, dctx, ctx, h1, idx, probs, dh1,
-                       dqk, S, causal, lo);
+                       dqk, S, causal, lo, dbk);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -486,8 +490,8 @@ extern "C" int32_t vipant_rows_ctx_fwd(const uint16_t* qk, const uint16_t* h1, c
 }
 
 extern "C" int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx, const uint16_t* ctx, const uint16_t* h1,
-                                       const int64_t* idx, const float* probs, uint16_t* dh1, uint16_t* dqk, int64_t batch, int64_t S,
-                                       int64_t H, int32_t causal, int32_t pair, void* stream) {
+                                       const int64_t* idx, const float* probs, uint16_t* dh1, uint16_t* dqk, float* dbk, int64_t batch,
+                                       int64_t S, int64_t H, int32_t causal, int32_t pair, void* stream) {
     if (int32_t e = check_ctx(batch, S, H)) return e;
     VIPANT_REQUIRE(qk != nullptr && dctx != nullptr && ctx != nullptr && h1 != nullptr && probs != nullptr && dh1 != nullptr && dqk != nullptr,
                    VIPANT_EBADSHAPE, "rows_ctx_bwd: null operand");
@@ -497,13 +501,13 @@ extern "C" int32_t vipant_rows_ctx_bwd(const uint16_t* qk, const uint16_t* dctx,
     hipStream_t st = (hipStream_t)stream;
     const int64_t lo = batch * H * H * 64;
     if (pair) {
-        if (H == 12) return launch_bwd<12, 3, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
-        if (H == 16) return launch_bwd<16, 4, 1, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
-        return launch_bwd<8, 2, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, st);
+        if (H == 12) return launch_bwd<12, 3, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, dbk, st);
+        if (H == 16) return launch_bwd<16, 4, 1, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, dbk, st);
+        return launch_bwd<8, 2, 2, true>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, lo, dbk, st);
     }
-    if (H == 12) return launch_bwd<12, 3, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
-    if (H == 16) return launch_bwd<16, 4, 1, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
-    return launch_bwd<8, 2, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, st);
+    if (H == 12) return launch_bwd<12, 3, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, dbk, st);
+    if (H == 16) return launch_bwd<16, 4, 1, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, dbk, st);
+    return launch_bwd<8, 2, 2, false>(a, b, c, d, idx, probs, (bf16_t*)dh1, (bf16_t*)dqk, (int)batch, (int)S, causal, 0, dbk, st);
 }
 
 extern "C" int32_t vipant_head_expand(const uint16_t* rows, uint16_t* out, int64_t n, int64_t H, void* stream) {

@@ -207,7 +207,8 @@ class Monitor(object):
             loss = self._forward_backward_micro(images, audios, text if self.with_text else None, mb)
         else:
             loss = self.model(images, audios, text if self.with_text else None)
-            loss.backward()
+            from . import ops
+            loss.backward(gradient=ops.unit_grad(loss.device) if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 else None)
         if self.grad_sync is not None:
             micro = getattr(self, "_micro_step", False)         # micro-batched step: nothing went through a per-block bucket
             self._micro_step = False

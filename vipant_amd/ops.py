@@ -358,8 +358,29 @@ def _producer(t: torch.Tensor, kind: str):
     return None
 
 
+_consts: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def _const(name: str, value: float, device) -> torch.Tensor:
+    """A 0-dim fp32 constant per device, created once (every `torch.zeros(())` / `ones_like(loss)` inside the step is a fill launch
+    on a dependent chain)."""
+    key = (name, device.index if device.index is not None else torch.cuda.current_device())
+    t = _consts.get(key)
+    if t is None:
+        t = _consts[key] = torch.full((), value, dtype=F32, device=device)
+    return t
+
+
+def unit_grad(device) -> torch.Tensor:
+    """d loss / d loss = 1 as a cached tensor: `loss.backward(gradient=ops.unit_grad(dev))` saves autograd's `ones_like` fill, and
+    InfoNCEFn.backward recognises it (by address) and skips the two multiplications by 1."""
+    return _const("one", 1.0, torch.device(device))
+
+
 def _placeholder(shape, device) -> torch.Tensor:
-    return torch.zeros((), dtype=F32, device=device).expand(*shape)
+    # ONE zero scalar per device serves every hand-off: the receiver only asks "is this the 4-byte allocation seen through zero
+    # strides?", and a gradient autograd has summed from several consumers never is
+    return _const("zero", 0.0, torch.device(device)).expand(*shape)
 
 
 def _is_placeholder(t: torch.Tensor, ph: torch.Tensor) -> bool:
@@ -423,7 +444,9 @@ class PatchEmbedFn(torch.autograd.Function):
         dw_eff = torch.empty((D, kcols), dtype=F32, device=dev)
         dconv = torch.empty(conv_shape, dtype=F32, device=dev) if mean_ch else dw_eff.view(conv_shape)
         dcls = torch.empty((D,), dtype=F32, device=dev)
-        dpos = torch.zeros(pos_shape, dtype=F32, device=dev)
+        dpos = torch.empty(pos_shape, dtype=F32, device=dev)      # rows 0 .. P are written by the kernel
+        if pos_shape[0] > P + 1:
+            dpos[P + 1:].zero_()                                  # a table longer than the sequence: the unused rows' gradient
         dlnw = torch.empty((D,), dtype=F32, device=dev)
         dlnb = torch.empty((D,), dtype=F32, device=dev)
         ws = scratch("patch_embed_bwd", query("vipant_patch_embed_ln_bwd_workspace_bytes", b, P, D, kcols), dev)
@@ -769,10 +792,9 @@ class BackboneFn(torch.autograd.Function):
                     gemm_tn(head_expand(do_r, H), hctx[0], d_wqkv[2 * D:], a_colsum=d_bqkv[2 * D:], ws_name="block_bwd")
                     dqk = torch.empty((2, batch * H, D), dtype=BF16, device=dev)
                     call("vipant_rows_ctx_bwd", qk.data_ptr(), dctx.data_ptr(), hctx.data_ptr(), h1.data_ptr(), _ptr(ridx),
-                         probs.data_ptr(), dh.data_ptr(), dqk.data_ptr(), batch, S, H, int(causal), 1, st)
+                         probs.data_ptr(), dh.data_ptr(), dqk.data_ptr(), d_bqkv[D:2 * D].data_ptr(), batch, S, H, int(causal), 1, st)
                     dq_r = wide_to_heads(dqk, wqkv_b_last[D:2 * D], H)
                     gemm_tn(head_expand(q_r, H), dqk[0], d_wqkv[D:2 * D], ws_name="block_bwd")
-                    d_bqkv[D:2 * D].zero_()
                     del dctx, dqk
                 else:
                     dqkv = torch.empty((M, 3 * D), dtype=BF16, device=dev)
@@ -1015,14 +1037,16 @@ class InfoNCEFn(torch.autograd.Function):
         B, E, row0, nrows, ls_shape = ctx.meta
         need = ctx.needs_input_grad
 
+        unit = dloss.dim() == 0 and dloss.data_ptr() == unit_grad(dloss.device).data_ptr()      # the trainer's cached 1.0
+
         def expand(d):
             if row0 == 0 and nrows == B:         # one replica: the slice is the batch (one launch instead of fill + mul + copy)
-                return d * dloss
+                return d if unit else d * dloss
             full = torch.zeros((B, E), dtype=F32, device=d.device)
             full[row0:row0 + nrows] = d * dloss
             return full
         return (expand(d1) if need[0] else None, expand(d2) if need[1] else None,
-                (dls * dloss).reshape(ls_shape) if need[2] else None, None, None, None, None)
+                (dls if unit else dls * dloss).reshape(ls_shape) if need[2] else None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------- LARS
@@ -1043,25 +1067,26 @@ class LarsState:
         self.p_ptrs = torch.tensor([p.data_ptr() for p in self.params], dtype=I64, device=dev)
         self.mu_ptrs = torch.tensor([m.data_ptr() for m in self.mu], dtype=I64, device=dev)
         self.ws = torch.empty((query("vipant_lars_workspace_bytes", n),), dtype=torch.uint8, device=dev)
-        self.g_ptrs = torch.empty((n,), dtype=I64, device=dev)
-        self.lr = torch.empty((n,), dtype=F32, device=dev)
-        self._host = [(torch.empty((n,), dtype=I64).pin_memory(), torch.empty((n,), dtype=F32).pin_memory(), None)
-                      for _ in range(2)] if dev.type == "cuda" else None
+        # gradient pointers (n x int64) and learning rates (n x fp32) in ONE staging buffer: one host-to-device copy per step
+        self.stage = torch.empty((12 * n,), dtype=torch.uint8, device=dev)
+        self.g_ptrs = self.stage[:8 * n].view(I64)
+        self.lr = self.stage[8 * n:].view(F32)
+        self._host = [(torch.empty((12 * n,), dtype=torch.uint8).pin_memory(), None) for _ in range(2)] if dev.type == "cuda" else None
         self._turn = 0
 
     def step(self, grads: Sequence[torch.Tensor], lrs: Sequence[float], weight_decay: float, momentum: float, eta: float):
         for p, g in zip(self.params, grads):
             assert g.is_contiguous() and g.dtype == F32 and g.shape == p.shape
-        hp, hl, ev = self._host[self._turn]
+        hb, ev = self._host[self._turn]
         if ev is not None:
             ev.synchronize()             # the copy issued from this buffer two steps ago (long done)
-        hp.copy_(torch.tensor([g.data_ptr() for g in grads], dtype=I64))
-        hl.copy_(torch.tensor(list(lrs), dtype=F32))
-        self.g_ptrs.copy_(hp, non_blocking=True)
-        self.lr.copy_(hl, non_blocking=True)
+        n = len(self.params)
+        hb[:8 * n].view(I64).copy_(torch.tensor([g.data_ptr() for g in grads], dtype=I64))
+        hb[8 * n:].view(F32).copy_(torch.tensor(list(lrs), dtype=F32))
+        self.stage.copy_(hb, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._host[self._turn] = (hp, hl, ev)
+        self._host[self._turn] = (hb, ev)
         self._turn ^= 1
         call("vipant_lars_step", self.p_ptrs.data_ptr(), self.g_ptrs.data_ptr(), self.mu_ptrs.data_ptr(), self.n.data_ptr(),
              self.adapt.data_ptr(), self.lr.data_ptr(), len(self.params), float(weight_decay), float(momentum), float(eta),
