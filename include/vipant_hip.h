@@ -203,13 +203,24 @@ int32_t vipant_cast_f32(const uint16_t* src, float* dst, int64_t n, void* stream
  * exponent with max|x[m, :]| / 2^e <= 448, q = round-to-nearest-even(x / 2^e).  K % 8 == 0, K <= 8192. */
 int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
                                void* stream);
-/* C[M, N] (bf16) = (A 2^(sa - 127)) (B 2^(sb - 127))^T (+ bias), A [M, K] and B [N, K] e4m3 with the row scales above, on
- * v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation; the row scales ride the instruction's block-scale operand).  Epilogues:
- * VIPANT_EPI_BF16, VIPANT_EPI_QUICKGELU_D8, VIPANT_EPI_DQUICKGELU_D8, meaning as in vipant_gemm_nt.  K % 128 == 0, K >= 256,
- * N % 8 == 0, leading dimensions (in elements = bytes) multiples of 16. */
+/* The block format for ACTIVATIONS (round 5; what v_mfma_scale_f32_16x16x128_f8f6f4's scale operands take): one power-of-two scale per
+ * 32 consecutive elements of a row, e = the smallest exponent with max|block| / 2^e <= 448, byte = e + 127, so that a producer can
+ * quantise the 32 columns it holds without knowing the rest of the row.  The scale bytes are stored in the order the contraction
+ * consumes them: byte of (row m, block kb = k / 32) at (((m / 128) * (K / 128) + kb / 4) * 16 + m % 16) * 32 + (kb % 4) * 8 + (m % 128) / 16;
+ * vipant_mx_scale_bytes(M, K) = ceil(M / 128) * (K / 128) * 512 bytes (0 if K % 128 != 0).  K % 128 == 0. */
+size_t vipant_mx_scale_bytes(int64_t M, int64_t K);
+int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                             void* stream);
+/* C[M, N] (bf16) = dequant(A, sa) dequant(B, sb)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation; the scales ride
+ * the instruction's block-scale operands).  A [M, K] e4m3: an activation, sa = its BLOCK scales (vipant_quant_e4m3_mx layout); B [N, K]
+ * e4m3: a weight matrix, sb = one scale per row (vipant_quant_e4m3_rows).  Epilogues: VIPANT_EPI_BF16, VIPANT_EPI_QUICKGELU_D8,
+ * VIPANT_EPI_DQUICKGELU_D8, meaning as in vipant_gemm_nt.  cq / cq_scale (both or neither; the two QuickGELU epilogues, N % 128 == 0):
+ * the epilogue ALSO leaves the e4m3 form of its bf16 result, bytes [M, N] + block scales -- vipant_quant_e4m3_mx of C bit for bit --
+ * i.e. the next contraction's A operand quantised where it is produced; with cq set and VIPANT_EPI_QUICKGELU_D8, C and aux may be
+ * NULL (only the e4m3 form is wanted).  K % 128 == 0, K >= 256, N % 8 == 0, leading dimensions (in elements = bytes) multiples of 16. */
 int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb,
-                            void* C, int64_t ldc, const float* bias, void* aux, int64_t M, int64_t N, int64_t K, int32_t epilogue,
-                            void* stream);
+                            void* C, int64_t ldc, const float* bias, void* aux, uint8_t* cq, uint8_t* cq_scale, int64_t M, int64_t N,
+                            int64_t K, int32_t epilogue, void* stream);
 /* conv1.weight [O, Cin, kh, kw] fp32 -> effective GEMM weight bf16 [O, Cout*kh*kw]; mean_channels != 0
  * averages the Cin stored channels into one (cvap/module/val.py:236-244), else Cout = Cin. */
 int32_t vipant_conv_weight_prep(const float* w, uint16_t* out, int64_t O, int64_t Cin, int64_t khw,
@@ -348,10 +359,12 @@ int32_t vipant_ln_mlp_quickgelu_bwd(const uint16_t* dy, const uint16_t* w_proj_t
 /* ---- The same block operators with e4m3 operands in their NT contractions (BASELINE.json configs[4], "fp8 MFMA weights") ----
  * `plan` carries the pre-quantised weights (vipant_quant_e4m3_rows of the SAME matrices, in the SAME orientation, as the bf16
  * weight arguments, which are then unused and may be NULL) and the scratch the operator quantises its activation into; every NT
- * contraction becomes quantise(activation rows) + vipant_gemm_nt_e4m3.  The weight-gradient contractions, LayerNorm, the
+ * contraction becomes vipant_gemm_nt_e4m3 on an activation block-quantised by its producer (a LayerNorm pass, the epilogue of the
+ * contraction before it) or, for the two attention outputs, by vipant_quant_e4m3_mx.  The weight-gradient contractions, LayerNorm, the
  * attention core and the residual stream are unchanged (bf16 / fp32).  plan == NULL: exactly the bf16 operator.
  * w_q / w_scale: the operator's (first) weight; w2_q / w2_scale: the second weight of the MLP operators (forward: w_fc then w_proj;
- * backward: w_proj_t then w_fc_t); act_q: bytes [M, 4D] (the widest activation); act_scale: bytes [M]. */
+ * backward: w_proj_t then w_fc_t), one scale per row; act_q: bytes [M, 4D] (the widest activation); act_scale: its block scales, one
+ * per 32 elements of a row in the MX layout of vipant_quant_e4m3_mx, vipant_mx_scale_bytes(M, 4D) bytes. */
 typedef struct vipant_fp8_plan {
     const uint8_t* w_q;
     const uint8_t* w_scale;
@@ -359,14 +372,20 @@ typedef struct vipant_fp8_plan {
     const uint8_t* w2_scale;
     uint8_t* act_q;
     uint8_t* act_scale;
-    /* backward operators, optional (both or neither): bytes [M, D] + [M] that accompany the bf16 stream gradient `dx_bf16` between
+    /* optional (both or neither), bytes [M, 4D] + vipant_mx_scale_bytes(M, 4D): where the epilogue of an MLP operator's first
+     * contraction (c_fc + QuickGELU forward, c_proj^T * QuickGELU' backward) leaves the e4m3 form of its result for the second one
+     * (round 5: the producer quantises, no pass over the [M, 4D] activation).  NULL: the result is block-quantised by a separate pass. */
+    uint8_t* emit_q;
+    uint8_t* emit_scale;
+    /* backward operators, optional (both or neither): bytes [M, D] + vipant_mx_scale_bytes(M, D) that accompany the bf16 stream gradient `dx_bf16` between
      * operators.  On entry they hold the quantised form of the incoming gradient (the operator's first contraction then skips its
      * quantisation pass); an operator that produces a new stream gradient (its LayerNorm backward) writes the new one's there. */
     uint8_t* dy_q;
     uint8_t* dy_scale;
 } vipant_fp8_plan;
-/* LayerNorm with the row quantisation of its bf16 output fused (the row is in registers anyway): q bytes [M, D] / qscale bytes [M]
- * = vipant_quant_e4m3_rows of y resp. dx_bf16, bit for bit; both NULL: exactly vipant_layernorm_fwd / vipant_layernorm_bwd. */
+/* LayerNorm with the block quantisation of its bf16 output fused (the row is in registers anyway): q bytes [M, D] / qscale bytes
+ * [vipant_mx_scale_bytes(M, D)] = vipant_quant_e4m3_mx of y resp. dx_bf16, bit for bit; both NULL: exactly vipant_layernorm_fwd /
+ * vipant_layernorm_bwd. */
 int32_t vipant_layernorm_fwd_e4m3(const void* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y, float* y_f32,
                                   float* mean, float* rstd, int64_t M, int64_t D, const uint16_t* add, void* sum_out, uint8_t* q,
                                   uint8_t* qscale, int32_t stream_flags, void* stream);

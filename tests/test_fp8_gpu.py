@@ -36,6 +36,50 @@ def dequant(q_u8, s_u8):
     return q_u8.view(torch.float8_e4m3fn).float() * torch.exp2(s_u8.float() - 127)[:, None]
 
 
+def emulate_quant_mx(x_bf16):
+    """the block format of the ACTIVATION operands (round 5): per 32 consecutive elements of a row, e = the smallest exponent with
+    amax / 2^e <= 448; q = rne(x / 2^e) in OCP e4m3.  Returns (q [M, K] float8, scale bytes [M, K / 32])."""
+    M, K = x_bf16.shape
+    x = x_bf16.float().view(M, K // 32, 32)
+    amax = x.abs().amax(dim=2)
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))) - 8
+    e = torch.where(amax * torch.exp2(-e) > 448, e + 1, e)
+    e = torch.where(amax > 0, e, torch.zeros_like(e)).clamp(-127, 127)
+    q = (x * torch.exp2(-e)[:, :, None]).to(torch.float8_e4m3fn).view(M, K)
+    return q, (e + 127).to(torch.uint8)
+
+
+def mx_scales(ops, s_tiled, M, K):
+    """the library's scale array (MX layout) -> scale bytes [M, K / 32]"""
+    return s_tiled[ops.mx_scale_index(M, K, s_tiled.device)]
+
+
+def dequant_mx(ops, q_u8, s_tiled):
+    M, K = q_u8.shape
+    sc = torch.exp2(mx_scales(ops, s_tiled, M, K).float() - 127)
+    return (q_u8.view(torch.float8_e4m3fn).float().view(M, K // 32, 32) * sc[:, :, None]).view(M, K)
+
+
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096), (129, 3072), (128, 128)])
+def test_block_quantiser_matches_the_stated_format(ops, M, K):
+    """vipant_quant_e4m3_mx bit for bit: bytes, and the scale bytes at their place in the MX layout."""
+    rows = torch.exp2(torch.randint(-12, 12, (M, 1), device=DEV).float())
+    x = (rnd(M, K, seed=M + K) * rows).to(torch.bfloat16)
+    x[:, 40:70] *= 64.0                                                                    # blocks of one row far apart in magnitude
+    x[0].zero_()                                                                           # an all-zero row
+    x[1, 3] = 448.0 * 2 ** 5                                                               # a block maximum exactly on the format's maximum
+    x[2, 32:64].zero_()                                                                    # an all-zero block
+    q, s = ops.quant_e4m3_mx(x)
+    assert s.numel() == ((M + 127) // 128) * (K // 128) * 512
+    q_ref, s_ref = emulate_quant_mx(x)
+    assert torch.equal(mx_scales(ops, s, M, K), s_ref)
+    assert torch.equal(q, q_ref.view(torch.uint8))
+    back = dequant_mx(ops, q, s)
+    blk = x.float().view(M, K // 32, 32)
+    rel = (back.view(M, K // 32, 32) - blk).abs().amax(dim=2) / blk.abs().amax(dim=2).clamp_min(1e-30)
+    assert float(rel.max()) <= 2 ** -4 + 1e-6                                              # half an ulp of the BLOCK maximum
+
+
 @pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096), (33, 5120), (17, 8192)])
 def test_quantiser_matches_the_stated_format(ops, M, K):
     rows = torch.exp2(torch.randint(-12, 12, (M, 1), device=DEV).float())                 # row magnitudes over 24 octaves
@@ -58,11 +102,12 @@ def test_e4m3_contraction_is_exact_on_its_operands(ops, M, N, K):
     a = (rnd(M, K, seed=1) * ra).to(torch.bfloat16)
     b = (rnd(N, K, seed=2) * rb * K ** -0.5).to(torch.bfloat16)
     bias = rnd(N, seed=3)
-    qa, sa = ops.quant_e4m3(a)
+    a[:, 64:96] *= 32.0                         # (blocks of a row at different scales: the per-K-tile scale words must line up)
+    qa, sa = ops.quant_e4m3_mx(a)
     qb, sb = ops.quant_e4m3(b)
     c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     ops.gemm_nt_e4m3(qa, sa, qb, sb, c, bias=bias)
-    ref = dequant(qa, sa).double() @ dequant(qb, sb).double().t() + bias.double()
+    ref = dequant_mx(ops, qa, sa).double() @ dequant(qb, sb).double().t() + bias.double()
     # bf16 output rounding only (2^-9 relative per element), row by row since the rows span 12 octaves
     err = ((c.double() - ref).abs() / ref.abs().amax(dim=1, keepdim=True)).max()
     assert float(err) < 2 ** -8, float(err)
@@ -76,12 +121,23 @@ def test_e4m3_quickgelu_epilogues(ops):
     a = rnd(M, K, seed=5).to(torch.bfloat16)
     w = (rnd(N, K, seed=6) * K ** -0.5).to(torch.bfloat16)
     bias = rnd(N, seed=7)
-    qa, sa = ops.quant_e4m3(a)
+    qa, sa = ops.quant_e4m3_mx(a)
     qw, sw = ops.quant_e4m3(w)
     g = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     code = torch.empty(M, N, dtype=torch.uint8, device=DEV)
     ops.gemm_nt_e4m3(qa, sa, qw, sw, g, bias=bias, aux=code, epi=ops.EPI_QUICKGELU_D8)
-    u = (dequant(qa, sa).double() @ dequant(qw, sw).double().t() + bias.double()).float()
+    # round 5: the same launch also leaving the e4m3 form of g (what c_proj reads) -- g and the codes unchanged, the bytes and the block
+    # scales exactly the stand-alone quantiser's of g; and alone (`running.recompute_mlp`: g and the codes are not wanted at all)
+    g2, code2 = torch.empty_like(g), torch.empty_like(code)
+    em = (torch.full((M, N), 77, dtype=torch.uint8, device=DEV), torch.full((ops.query("vipant_mx_scale_bytes", M, N),), 77, dtype=torch.uint8, device=DEV))
+    ops.gemm_nt_e4m3(qa, sa, qw, sw, g2, bias=bias, aux=code2, epi=ops.EPI_QUICKGELU_D8, emit=em)
+    assert torch.equal(g, g2) and torch.equal(code, code2)
+    gq, gs = ops.quant_e4m3_mx(g)
+    assert torch.equal(em[0], gq) and torch.equal(mx_scales(ops, em[1], M, N), mx_scales(ops, gs, M, N))
+    em2 = (torch.full_like(em[0], 78), torch.full_like(em[1], 78))
+    ops.gemm_nt_e4m3(qa, sa, qw, sw, None, bias=bias, epi=ops.EPI_QUICKGELU_D8, emit=em2)
+    assert torch.equal(em2[0], gq) and torch.equal(mx_scales(ops, em2[1], M, N), mx_scales(ops, gs, M, N))
+    u = (dequant_mx(ops, qa, sa).double() @ dequant(qw, sw).double().t() + bias.double()).float()
     ub = u.to(torch.bfloat16).float()                                             # the epilogue sees the bf16-rounded pre-activation
     sg = torch.sigmoid(1.702 * ub)
     assert float(((g.float() - ub * sg).abs() / (ub * sg).abs().amax()).max()) < 2 ** -7       # one bf16 ulp of u at the top of the range
@@ -90,13 +146,17 @@ def test_e4m3_quickgelu_epilogues(ops):
     # backward form: dg (bf16, quantised here) x W^T with the derivative code applied
     dy = rnd(M, K, seed=8).to(torch.bfloat16)
     wt = w.t().contiguous()                                                       # [K, N]: rows of the transposed weight
-    qd, sd = ops.quant_e4m3(dy)
-    qt, st = ops.quant_e4m3(wt)
+    qd, sd = ops.quant_e4m3_mx(dy)
     # du[M, N] = dy[M, K] @ w[N, K]^T needs B = w as [N, K] rows: the same operand as the forward
     du = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     ops.gemm_nt_e4m3(qd, sd, qw, sw, du, aux=code, epi=ops.EPI_DQUICKGELU_D8)
-    ref = (dequant(qd, sd).double() @ dequant(qw, sw).double().t()).float().to(torch.bfloat16).float() * (code.float() / 212.5 - 0.1)
+    ref = (dequant_mx(ops, qd, sd).double() @ dequant(qw, sw).double().t()).float().to(torch.bfloat16).float() * (code.float() / 212.5 - 0.1)
     assert float(((du.float() - ref).abs() / ref.abs().amax()).max()) < 2 ** -7
+    du2 = torch.empty_like(du)
+    em3 = (torch.full_like(em[0], 79), torch.full_like(em[1], 79))
+    ops.gemm_nt_e4m3(qd, sd, qw, sw, du2, aux=code, epi=ops.EPI_DQUICKGELU_D8, emit=em3)          # ... and du's e4m3 form beside du
+    dq, ds = ops.quant_e4m3_mx(du)
+    assert torch.equal(du, du2) and torch.equal(em3[0], dq) and torch.equal(mx_scales(ops, em3[1], M, N), mx_scales(ops, ds, M, N))
 
 
 def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
@@ -147,9 +207,9 @@ def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
 
 
 @pytest.mark.parametrize("D", [768, 1024])
-def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
-    """vipant_layernorm_{fwd,bwd}_e4m3: the bytes and row scales written beside the bf16 output are exactly what
-    vipant_quant_e4m3_rows makes of that output (so fusing the pass changes nothing downstream)."""
+def test_layernorm_fused_block_quantisation_is_the_standalone_one(ops, D):
+    """vipant_layernorm_{fwd,bwd}_e4m3: the bytes and block scales written beside the bf16 output are exactly what
+    vipant_quant_e4m3_mx makes of that output (so fusing the pass changes nothing downstream)."""
     M = 1000
     x = rnd(M, D, seed=31) * torch.exp2(torch.randint(-4, 5, (M, 1), device=DEV).float())
     add = rnd(M, D, seed=32).to(torch.bfloat16)
@@ -158,12 +218,12 @@ def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
     xs = torch.empty(M, D, device=DEV)
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     q = torch.empty(M, D, dtype=torch.uint8, device=DEV)
-    qs = torch.empty(M, dtype=torch.uint8, device=DEV)
+    qs = torch.empty(ops.query("vipant_mx_scale_bytes", M, D), dtype=torch.uint8, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     ops.call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, mean.data_ptr(),
              rstd.data_ptr(), M, D, add.data_ptr(), xs.data_ptr(), q.data_ptr(), qs.data_ptr(), 0, st)
-    q_ref, s_ref = ops.quant_e4m3(y)
-    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
+    q_ref, s_ref = ops.quant_e4m3_mx(y)
+    assert torch.equal(q, q_ref) and torch.equal(mx_scales(ops, qs, M, D), mx_scales(ops, s_ref, M, D))
     y_plain = ops.layernorm_fwd(x, gamma, beta, add=add, want_sum=True)[0]
     assert torch.equal(y, y_plain)
     # backward, bf16 gradient stream in place
@@ -175,8 +235,8 @@ def test_layernorm_fused_row_quantisation_is_the_standalone_one(ops, D):
     ops.call("vipant_layernorm_bwd_e4m3", dy.data_ptr(), 2, xs.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
              dxb.data_ptr(), None, D, dxb.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(),
              q.data_ptr(), qs.data_ptr(), st)
-    q_ref, s_ref = ops.quant_e4m3(dxb)
-    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
+    q_ref, s_ref = ops.quant_e4m3_mx(dxb)
+    assert torch.equal(q, q_ref) and torch.equal(mx_scales(ops, qs, M, D), mx_scales(ops, s_ref, M, D))
     ops.call("vipant_layernorm_bwd", dy.data_ptr(), 2, xs.data_ptr(), D, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
              dxb2.data_ptr(), None, D, dxb2.data_ptr(), dg.data_ptr(), db.data_ptr(), cs.data_ptr(), 0, M, D, ws.data_ptr(), ws.numel(), st)
     assert torch.equal(dxb, dxb2)
@@ -211,8 +271,8 @@ def test_e4m3_stack_with_recomputed_mlp_is_bit_identical(ops):
 def test_e4m3_block_width_1024_against_oracle():
     """BASELINE.json configs[4] width (ViT-L: 1024, 16 heads) with e4m3 contractions against the CPU ORACLE (oracle/ref_cpu.py, fp32
     restatement of cvap/module/val.py:468-522), not against the bf16 HIP run: two blocks forward + backward at S = 50.  The
-    reference has no fp8 path, so the budgets are about twice what MI355X shows for this format (per-row power-of-two scales,
-    e4m3 operands in the eight NT contractions of a block); the bf16 stack on the same weights is checked beside it so that the
+    reference has no fp8 path, so the budgets are about twice what MI355X shows for this format (e4m3 operands in the eight NT
+    contractions of a block: activations with one power-of-two scale per 32 elements, weights one per row); the bf16 stack on the same weights is checked beside it so that the
     e4m3 budget can be read as "bf16 error x k"."""
     import vipant_amd.module as Mod
     from oracle import ref_cpu as R

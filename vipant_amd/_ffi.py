@@ -28,7 +28,7 @@ _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_siz
 class Fp8Plan(C.Structure):
     """struct vipant_fp8_plan (include/vipant_hip.h): e4m3 weights + activation scratch of one fused block operator call."""
     _fields_ = [("w_q", _p), ("w_scale", _p), ("w2_q", _p), ("w2_scale", _p), ("act_q", _p), ("act_scale", _p),
-                ("dy_q", _p), ("dy_scale", _p)]
+                ("emit_q", _p), ("emit_scale", _p), ("dy_q", _p), ("dy_scale", _p)]
 
 
 # name -> (restype, argtypes); mirrors include/vipant_hip.h one to one
@@ -65,7 +65,9 @@ PROTOTYPES = {
     "vipant_cast_bf16_multi": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "vipant_cast_f32": (_i32, [_p, _p, _i64, _p]),
     "vipant_quant_e4m3_rows": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
-    "vipant_gemm_nt_e4m3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_gemm_nt_e4m3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mx_scale_bytes": (_sz, [_i64, _i64]),
+    "vipant_quant_e4m3_mx": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "vipant_conv_weight_prep": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_im2col": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),

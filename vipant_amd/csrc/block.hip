@@ -21,20 +21,22 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
         if (_rc != VIPANT_OK) return _rc; \
     } while (0)
 
-// a . w^T on the bf16 operands, or -- with a plan -- on their e4m3 forms: `a` is row-quantised into the plan's scratch first, the
-// weight comes pre-quantised (wq / ws: the plan's copy of the SAME matrix, same orientation, as the bf16 argument it replaces)
-// (aq, as): the activation already quantised (by the LayerNorm that produced it), or NULL: quantise it here
+// a . w^T on the bf16 operands, or -- with a plan -- on their e4m3 forms: the weight comes pre-quantised (wq / ws: the plan's copy
+// of the SAME matrix, same orientation, as the bf16 argument it replaces, one scale per row); the activation in MX block format
+// (common.h): (aq, as) = already quantised by its producer (a LayerNorm pass, the epilogue of the contraction before), or NULL:
+// block-quantised here into the plan's scratch.  (cq, cqs) != NULL: the epilogue also leaves the e4m3 form of the result there (MX
+// scales) for the next contraction; `out` / `aux` may then be NULL (QuickGELU epilogue: only the e4m3 form is wanted).
 int32_t nt(const vipant_fp8_plan* plan, const uint8_t* wq, const uint8_t* ws, const uint8_t* aq, const uint8_t* as,
            const uint16_t* a, const uint16_t* w, void* out, const float* bias, void* aux, int64_t M, int64_t N, int64_t K,
-           int32_t epi, void* stream) {
+           int32_t epi, void* stream, uint8_t* cq = nullptr, uint8_t* cqs = nullptr) {
     if (plan == nullptr) return vipant_gemm_nt(a, K, w, K, out, N, bias, aux, 1.0f, M, N, K, epi, stream);
     VIPANT_REQUIRE(wq != nullptr && ws != nullptr && plan->act_q != nullptr && plan->act_scale != nullptr, VIPANT_EBADSHAPE,
                    "fp8 plan: quantised weight, its row scales and the activation scratch are all required");
     if (aq == nullptr) {
-        TRY(vipant_quant_e4m3_rows(a, K, plan->act_q, K, plan->act_scale, M, K, stream));
+        TRY(vipant_quant_e4m3_mx(a, K, plan->act_q, K, plan->act_scale, M, K, stream));
         aq = plan->act_q; as = plan->act_scale;
     }
-    return vipant_gemm_nt_e4m3(aq, K, as, wq, K, ws, out, N, bias, aux, M, N, K, epi, stream);
+    return vipant_gemm_nt_e4m3(aq, K, as, wq, K, ws, out, N, bias, aux, cq, cqs, M, N, K, epi, stream);
 }
 
 // LayerNorm backward of a block operator: in place on the stream gradient (fp32 master + bf16 copy, or bf16 only), the new
@@ -154,10 +156,15 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const void* x, const uint16_
     VIPANT_REQUIRE((add == nullptr) == (x_out == nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: add and x_out go together");
     TRY(vipant_layernorm_fwd_e4m3(x, D, gamma, beta, h, nullptr, mean, rstd, M, D, add, x_out, plan ? plan->act_q : nullptr,
                                   plan ? plan->act_scale : nullptr, stream_flags, stream));
+    // with a plan the c_fc epilogue leaves g's e4m3 form (block scales) in the plan's emit buffers and c_proj reads it from there: no
+    // quantisation pass over the [M, 4D] activation; `g` / `dcode` may then be NULL (`running.recompute_mlp`: neither is kept)
+    const bool emit = plan != nullptr && plan->emit_q != nullptr;
+    VIPANT_REQUIRE(emit || (g != nullptr && dcode != nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: g and dcode are required");
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
-           plan ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream));
-    return nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, g, w_proj, y, b_proj, nullptr, M,
-              D, 4 * D, VIPANT_EPI_BF16, stream);
+           plan ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream,
+           emit ? plan->emit_q : nullptr, emit ? plan->emit_scale : nullptr));
+    return nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, emit ? plan->emit_q : nullptr,
+              emit ? plan->emit_scale : nullptr, g, w_proj, y, b_proj, nullptr, M, D, 4 * D, VIPANT_EPI_BF16, stream);
 }
 
 extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* add, float* x_out, const float* gamma,
@@ -196,17 +203,18 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
     // sum the caller already has)
     // (VIPANT_STREAM_FEW_ROWS: the operator runs on a batch's read-out rows -- bf16 only: the e4m3 contractions have one kernel)
     const int32_t few = (plan == nullptr && (stream_flags & VIPANT_STREAM_FEW_ROWS)) ? VIPANT_EPI_FEW_ROWS : 0;
+    const bool emit = plan != nullptr && plan->emit_q != nullptr;     // du's e4m3 form straight from the epilogue that makes du
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
            plan ? plan->dy_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
-           VIPANT_EPI_DQUICKGELU_D8 | few, stream));
+           VIPANT_EPI_DQUICKGELU_D8 | few, stream, emit ? plan->emit_q : nullptr, emit ? plan->emit_scale : nullptr));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
     // (Order, round 5: both input-gradient contractions first, then both weight gradients.  The NT kernels walk their tiles by
     // tickets and lose 1/256 of a launch per CU another stream holds; a weight-gradient launch is one wave of <= 256 long
     // workgroups and waits for a held CU.  The replica group's bucket all-reduce starts at a block boundary, i.e. right here: the
     // first 1.5 ms of a block's backward are now the two launches that tolerate it.  du is also read while it is still in the
     // 256 MB cache.)
-    TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, nullptr, nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D,
-           4 * D, VIPANT_EPI_BF16 | few, stream));
+    TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, emit ? plan->emit_q : nullptr,
+           emit ? plan->emit_scale : nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D, 4 * D, VIPANT_EPI_BF16 | few, stream));
     TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
     TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias

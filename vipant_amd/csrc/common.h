@@ -88,6 +88,18 @@ static inline int device_cus() {
     return c > 0 ? c : 256;
 }
 
+// ---- MX block scales of an e4m3 activation operand (round 5) --------------------------------------
+// The A operand [M, K] of vipant_gemm_nt_e4m3 carries one power-of-two scale (E8M0 byte, value 2^(byte - 127)) per 32 consecutive k of a
+// row -- the block format v_mfma_scale_f32_16x16x128_f8f6f4 takes -- so that a PRODUCER can quantise what it has in hand (a tile
+// epilogue's 32 columns, a LayerNorm lane group) without knowing the rest of the row.  The bytes are stored in the order the
+// contraction's waves consume them: for the 128-row group G = m / 128 and the K-tile kt = k / 128, lane (r = m % 16, q = (k % 128) / 32)
+// of a wave finds the bytes of its eight 16-row tiles i = (m % 128) / 16 as ONE 8-byte word -- 512 contiguous bytes per wave and K-tile.
+// Size: ceil(M / 128) * (K / 128) * 512 bytes (K % 128 == 0); bytes of rows >= M are never used for a stored result.
+__host__ __device__ static inline int64_t mx_scale_offset(int64_t m, int kb /* = k / 32 */, int kt_per_row /* = K / 128 */) {
+    return (((m >> 7) * kt_per_row + (kb >> 2)) * 16 + (m & 15)) * 32 + (kb & 3) * 8 + ((m >> 4) & 7);
+}
+static inline size_t mx_scale_bytes(int64_t M, int64_t K) { return (size_t)ceil_div(M, 128) * (size_t)(K / 128) * 512; }
+
 // ---- ticket walk of the persistent kernels ------------------------------------------------------
 // A persistent grid that walks its tiles with a static stride assumes that all of its workgroups start together: a workgroup that
 // finds its CU held by another stream's kernel (the RCCL all-reduce of a gradient bucket, vipant_amd/parallel.py) starts when
@@ -104,6 +116,34 @@ uint32_t* vipant_ticket_block(hipStream_t stream, uint32_t** other);        // n
 
 // ---- device helpers -----------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// the shared exponent of a block: the smallest e with amax / 2^e <= 448 (the largest e4m3 value); `inv` = 2^-e
+__device__ __forceinline__ int mx_exponent(float amax, float* inv) {
+    int e = 0;
+    if (amax > 0.f) {
+        e = (int)((__float_as_uint(amax) >> 23) & 255u) - 127 - 8;            // floor(log2(amax)) - 8: amax / 2^e in [256, 512)
+        if (amax * __uint_as_float((uint32_t)(127 - e) << 23) > 448.f) e += 1;
+        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+    }
+    *inv = __uint_as_float((uint32_t)(127 - e) << 23);
+    return e;
+}
+// maximum over the 2 / 4 / 8 consecutive lanes that share a block (DPP row operations: no LDS traffic)
+template <int NL>
+__device__ __forceinline__ float mx_lane_max(float v) {
+    static_assert(NL == 2 || NL == 4 || NL == 8, "lanes per block");
+#define VIPANT_MAXD(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false)))
+    VIPANT_MAXD(0xB1);                          // quad_perm [1, 0, 3, 2]: xor 1
+    if (NL >= 4) VIPANT_MAXD(0x4E);             // quad_perm [2, 3, 0, 1]: xor 2
+#undef VIPANT_MAXD
+    if (NL == 8) v = fmaxf(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+__device__ __forceinline__ int mx_pack4(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
 
 namespace tickets {
 __device__ __forceinline__ uint32_t take(uint32_t* p, uint32_t n = 1u) {

@@ -420,7 +420,46 @@ __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __re
     }
 }
 
+// bf16 rows -> e4m3 with one power-of-two scale per 32 consecutive elements of a row (the MX block format, common.h): a thread takes 8
+// elements, the four threads of a block agree on the exponent through DPP.  Purely streaming: no row-wide reduction.
+__global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                            int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K) {
+    const int cpr = K / 8;                               // 16-byte chunks per row (a multiple of 4)
+    const int64_t total = M * cpr;
+    const int64_t span = (int64_t)gridDim.x * 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += span) {
+        const int64_t c = base + threadIdx.x;             // whole quads are in or out: total % 4 == 0 and base % 4 == 0
+        if (c >= total) break;
+        const int64_t row = c / cpr;
+        const int col = (int)(c - row * cpr) * 8;
+        const bf16x8 v = *(const bf16x8*)(x + row * ldx + col);
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
+        amax = mx_lane_max<4>(amax);
+        float inv;
+        const int e = mx_exponent(amax, &inv);
+        *(int2*)(q + row * ldq + col) = int2{mx_pack4((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
+                                             mx_pack4((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
+        if ((threadIdx.x & 3) == 0) scale[mx_scale_offset(row, col >> 5, K >> 7)] = (uint8_t)(e + 127);
+    }
+}
+
 }  // namespace
+
+extern "C" size_t vipant_mx_scale_bytes(int64_t M, int64_t K) { return K > 0 && K % 128 == 0 && M > 0 ? mx_scale_bytes(M, K) : 0; }
+
+extern "C" int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                        void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+    VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr,
+                   VIPANT_EALIGN, "quant_e4m3_mx: misaligned rows");
+    const int64_t blocks = ceil_div(M * (K / 8), 256);
+    hipLaunchKernelGGL(quant_e4m3_mx_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,
                                           int64_t K, void* stream) {

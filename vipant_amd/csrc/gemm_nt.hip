@@ -22,7 +22,9 @@ struct GemmNT {
     int M, N, K;
     float alpha;
     int dbg;   // VIPANT_GEMM_VARIANT (timing experiments only): bit 0 = skip the epilogue stores
-    const uint8_t* sa; const uint8_t* sb;    // fp8 operands only: per-row E8M0 exponents of A and B (value = e4m3 * 2^(byte - 127))
+    // fp8 operands only: E8M0 exponents (value = e4m3 * 2^(byte - 127)) -- A: one per 32 consecutive k of a row, in the MX layout of
+    // common.h; B (a weight matrix): one per row
+    const uint8_t* sa; const uint8_t* sb;
     // token assembly (EPI_F32 of the plain kernel only; ViTPreEncoder, cvap/module/val.py:249-257): with tok_p > 0, row m = (item,
     // patch) of the product lands in row item * (tok_p + 1) + patch + 1 of C and gets pos[patch + 1, :] added -- the patch
     // embedding written straight into the token matrix, whose class-token rows a one-row-per-item kernel fills
@@ -37,6 +39,10 @@ struct GemmNT {
     // elements behind the hi plane; 0: a single bf16 plane).  A pair in A doubles the K range (both planes against the same B rows);
     // a pair in C keeps 16 of the accumulator's 24 mantissa bits.
     int64_t a_lo = 0, c_lo = 0;
+    // e4m3 kernels with EMIT: the epilogue also leaves the e4m3 form of its bf16 result [M, N] (bytes `cq`, MX block scales `cqs`) -- the A
+    // operand of the next contraction, quantised where it is produced.  With cq set, C (and the code matrix `aux` of the QuickGELU
+    // epilogue) may be NULL: only the e4m3 form is wanted (`running.recompute_mlp`: the forward keeps neither g nor the codes).
+    uint8_t* cq = nullptr; uint8_t* cqs = nullptr;
 };
 
 template <int EPI>
@@ -388,10 +394,23 @@ __device__ __forceinline__ void load_codes(const GemmNT& p, int m0, int n0, int 
 
 // `pre`: the codes of round 0, requested by the caller during the tile's last K-tile (QuickGELU' launch on the DEEP schedule: the
 // HBM round trip of the first round's codes is then off the epilogue's critical path), or NULL
-template <int EPI>
+template <int EPI, bool EMIT = false>
 __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], const f32x4 (&bv)[4], char* stg, char* stg_hi,
                                             int m0, int n0, int grp, int wl, int frow, int fq, int tid,
                                             const u32x2 (*pre)[4] = nullptr) {
+    // EMIT: 8 consecutive bf16 results of row m from column n on (n % 8 == 0; the four threads of a 32-column block are four
+    // consecutive lanes, all inside the bounds together since N % 32 == 0) -> e4m3 bytes + the block's scale (MX layout, common.h)
+    auto emit8 = [&](const bf16x8& val, int m, int n, int ch) {
+        float f[8], amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f[e] = (float)val[e]; amax = fmaxf(amax, fabsf(f[e])); }
+        amax = mx_lane_max<4>(amax);
+        float inv;
+        const int ex = mx_exponent(amax, &inv);
+        *(int2*)(p.cq + (int64_t)m * p.N + n) = int2{mx_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
+                                                      mx_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv)};
+        if ((ch & 3) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)(ex + 127);
+    };
     // rows 0-15 of a round are staged at `stg`, rows 16-31 at `stg_hi` (the ring kernel has two free 8-KiB pieces, not one of 16)
     stg_hi -= 16 * 512;
     auto sync = [&]() {
@@ -455,10 +474,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                 if (m < p.M && n < p.N && !(p.dbg & 1)) {
                     const int64_t o = (int64_t)m * p.ldc + n;
                     uint32_t cw[4];
+                    bf16x8 g2[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const bf16x8 v = *(const bf16x8*)((R & 16 ? stg_hi : stg) + R * 512 + (((cp * 2 + h) ^ (R & 15)) << 4));
-                        bf16x8 g;
+                        bf16x8& g = g2[h];
                         cw[h * 2] = cw[h * 2 + 1] = 0u;
                         // two elements per instruction (v_pk_mul / v_pk_add / v_pk_fma): this epilogue is bound by its own
                         // arithmetic as much as by its stores.  code = 212.5 (sg + 1.702 ge (1 - sg)) + 21.25, constants folded.
@@ -476,9 +496,22 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                             w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
                             w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
                         }
-                        *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
+                        if (!EMIT || p.C != nullptr) *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
                     }
-                    *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
+                    if (!EMIT || p.aux != nullptr) *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
+                    if (EMIT) {         // 16 columns per thread: two threads per 32-column block
+                        float f[16], amax = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { f[e] = (float)g2[e >> 3][e & 7]; amax = fmaxf(amax, fabsf(f[e])); }
+                        amax = mx_lane_max<2>(amax);
+                        float inv;
+                        const int ex = mx_exponent(amax, &inv);
+                        *(i32x4*)(p.cq + (int64_t)m * p.N + n) = i32x4{mx_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
+                                                    mx_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv),
+                                                    mx_pack4(f[8] * inv, f[9] * inv, f[10] * inv, f[11] * inv),
+                                                    mx_pack4(f[12] * inv, f[13] * inv, f[14] * inv, f[15] * inv)};
+                        if ((cp & 1) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)(ex + 127);
+                    }
                 }
             }
             sync();
@@ -494,6 +527,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                 const int64_t o = (int64_t)m * p.ldc + n;
                 if (EPI == VIPANT_EPI_BF16) {
                     *(bf16x8*)((bf16_t*)p.C + o) = v;
+                    if (EMIT) emit8(v, m, n, ch);
                 } else if (GELU_OUT) {
                     bf16x8 g;
                     uint32_t code[8];
@@ -504,12 +538,14 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                         g[e] = (bf16_t)(u * sg);
                         code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
                     }
-                    if (D8)
+                    if (EMIT && p.aux == nullptr) {
+                    } else if (D8)
                         *(u32x2*)((uint8_t*)p.aux + o) = u32x2{code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24,
                                                                code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
                     else
                         *(bf16x8*)((bf16_t*)p.aux + o) = v;
-                    *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    if (!EMIT || p.C != nullptr) *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    if (EMIT) emit8(g, m, n, ch);
                 } else {  // QuickGELU'
                     bf16x8 d;
 #pragma unroll
@@ -525,6 +561,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                         d[e] = (bf16_t)((float)v[e] * dg);
                     }
                     *(bf16x8*)((bf16_t*)p.C + o) = d;
+                    if (EMIT) emit8(d, m, n, ch);
                 }
             }
         }
@@ -547,7 +584,7 @@ template <int V> struct Int { static constexpr int value = V; };
 // ES = bytes per operand element: 2 = bf16 (K-tile of 64), 1 = e4m3 with per-row power-of-two scales (K-tile of 128: the same
 // 128-byte rows, the same LDS images, DMA stream and barrier schedule; half the MFMA instructions, each twice as long, for
 // twice the K -- twice the FLOP per byte moved and per cycle).
-template <int EPI, int VAR, int ES = 2>
+template <int EPI, int VAR, int ES = 2, bool EMIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -576,7 +613,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // mailbox (two words, alternating), and every wave reads that word in the bias round trip of the tile after that.  A workgroup
     // therefore holds claims on three tiles beyond the one it computes.  (gemm_nt.hip is compiled with the atomic optimizer off:
     // it turns a uniform atomic into "first lane adds, wait, broadcast" -- a full wait where the draw is issued.)
-    const bool dyn = p.tk != nullptr;
+    // (the e4m3 QuickGELU kernel keeps the static walk: it sits at the 256-register limit, and the ticket state is what spills)
+    const bool dyn = (ES != 1 || EPI != VIPANT_EPI_QUICKGELU_D8) && p.tk != nullptr;
     constexpr int NO_TILE = 0x3FFFFFFF;
     const int xq = blockIdx.x & 7;
     int qlen_own;
@@ -709,18 +747,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // column tiles) are read in the first interval and kept; A fragments run one row tile (four MFMAs, 128 cycles) ahead.
     i32x8 gb[4], ga[2];
     uint32_t sav[2] = {0x7F7F7F7Fu, 0x7F7F7F7Fu}, sbv = 0x7F7F7F7Fu, sav_n[2] = {0x7F7F7F7Fu, 0x7F7F7F7Fu}, sbv_n = 0x7F7F7F7Fu;
-    auto load_scales = [&](const TileDesc& d, uint32_t (&a2)[2], uint32_t& b1) {     // row tile i -> byte i, column tile j -> byte j
-        a2[0] = a2[1] = b1 = 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = d.m0 + grp * 128 + i * 16 + frow;
-            a2[i >> 2] |= (uint32_t)(m < p.M ? p.sa[m] : (uint8_t)127) << ((i & 3) * 8);
-        }
+    // B (weights): one exponent per row, column tile j -> byte j, once per tile.  A (activations): one exponent per row and 32 k (MX
+    // layout, common.h): the bytes of this lane's eight row tiles for ONE K-tile are one 8-byte word, row tile i -> byte i, fetched a
+    // K-tile ahead -- issued in front of the K-tile's DMA pieces, i.e. older than all of them, so that the counted waits at the end of
+    // the K-tile cover it (the interval-0 waits allow one more request in flight for it).
+    auto load_b_scales = [&](const TileDesc& d, uint32_t& b1) {
+        b1 = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = d.n0 + wl * 64 + j * 16 + frow;
             b1 |= (uint32_t)(n < p.N ? p.sb[n] : (uint8_t)127) << (j * 8);
         }
+    };
+    const int kts = p.K >> 7;
+    const int64_t groups = ((int64_t)p.M + 127) >> 7;
+    auto load_a_scales = [&](const TileDesc& d, int kt, uint32_t (&a2)[2]) {
+        const int64_t G = (int64_t)(d.m0 >> 7) + grp;
+        u32x2 v = u32x2{0x7F7F7F7Fu, 0x7F7F7F7Fu};
+        if (d.abytes != 0 && G < groups) v = *(const u32x2*)(p.sa + ((G * kts + kt) * 16 + frow) * 32 + fq * 8);
+        a2[0] = v[0]; a2[1] = v[1];
     };
     auto frag_head8 = [&](auto hc, int stage, int slot) {
         constexpr int h = decltype(hc)::value;
@@ -769,7 +814,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     TileDesc cur = describe(tile), nxt = describe(tile_nxt);
     int gk = 0, slot = 0;                       // K-tile counter of the stream: A stage = gk & 1, B slot = gk % 3
     if (ES == 1) {
-        load_scales(cur, sav, sbv);
+        load_a_scales(cur, 0, sav);
+        load_b_scales(cur, sbv);
         asm volatile("" : "+v"(sav[0]), "+v"(sav[1]), "+v"(sbv));             // awaited before any DMA is in flight
     }
     if (DEEP) {     // K-tile 0 (A, B), K-tile 1 (B; A rows 0-63): what the steady state would have issued before K-tile 0
@@ -819,10 +865,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             if (dyn && k == nk - 2) tk_next = tickets::peek(mbox + tk_par);
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
-                if (ES == 1) load_scales(nxt, sav_n, sbv_n);                  // the next tile's scales ride the same round trip
+                if (ES == 1) load_b_scales(nxt, sbv_n);                       // the next tile's weight scales ride the same round trip
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
-                if (ES == 1) asm volatile("" : "+v"(sav_n[0]), "+v"(sav_n[1]), "+v"(sbv_n));
+                if (ES == 1) asm volatile("" : "+v"(sbv_n));
                 if (dyn) {      // older than the loads above: awaited with them, and kept as a scalar from here (a vector register that
                     asm volatile("" : "+v"(tk_next));     // "may be pending" costs a vmcnt wait behind the epilogue's stores)
                     tk_next_s = __builtin_amdgcn_readfirstlane((int)tk_next);
@@ -836,6 +882,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 // (issued behind the waits above -- the code bytes come from HBM -- and not awaited here)
                 if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);
             }
+            if (ES == 1) {      // the A scales of the stream's next K-tile
+                const bool w1 = k + 1 >= nk;
+                load_a_scales(w1 ? nxt : cur, w1 ? 0 : k + 1, sav_n);
+            }
             if (DEEP) {
                 // interval 0 (row tiles 0-3): B rows of K-tile k+2 (its slot was last read one interval ago by the lagging group),
                 // A rows 64-127 of K-tile k+1 (their half-stage was consumed in the previous interval); interval 1 (row tiles 4-7):
@@ -848,7 +898,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 __builtin_amdgcn_sched_barrier(0);
                 frag_head8(Int<0>{}, stage, slot);
                 half_body8(Int<0>{}, stage);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (ES == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");       // (+ the A-scale word of the next K-tile)
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 sync();
                 fill_a_half(make_rsrc(w2 ? nxt.a : cur.a, w2 ? nxt.abytes : cur.abytes), stage, 0, k2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -878,7 +929,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 frag_head(0, stage, slot);
                 if (ES == 1) half_body8(Int<0>{}, stage); else
                 half_body(0, stage);
-                if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (grp == 1) {
+                    if (ES == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // (+ the A-scale word of the next K-tile)
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
                 sync();
                 // second interval: k-step 1
                 if (ES == 1) frag_head8(Int<1>{}, stage, slot); else
@@ -891,28 +945,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             }
             ++gk;
             slot = slot1;
+            if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; }
         }
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
         if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(p.tk + xq);        // not awaited here
-        pp_epilogue<EPI>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
+        pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile = tile_nxt;
         tile_nxt = (dyn && !tk_first) ? tk_next_s : tile_nxt + G;
         tk_first = false;
         cur = nxt;
         nxt = describe(tile_nxt);
-        if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; sbv = sbv_n; }
+        if (ES == 1) sbv = sbv_n;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
     if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
 }
 
-template <int EPI, int VAR, int ES = 2>
+template <int EPI, int VAR, int ES = 2, bool EMIT = false>
 int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     static DeviceOnce once;
     if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES, EMIT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
         done_on_device(once);
     }
@@ -925,11 +980,11 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     const int64_t ppx = (ntm + 3) / 4;
     const int64_t shortest = VAR == 8 ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
                                       : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
-    if (grid == 256 && shortest > 96 && !(p.dbg & 4194304)) {          // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
+    if (grid == 256 && shortest > 96 && !(p.dbg & 4194304) && !(ES == 1 && EPI == VIPANT_EPI_QUICKGELU_D8)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
         p.tk = vipant_ticket_block(stream, &p.tk_other);
         if (p.tk == nullptr) return VIPANT_EHIP;
     }
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES, EMIT>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -1218,8 +1273,8 @@ extern "C" int32_t vipant_gemm_nt_tokens(const uint16_t* A, int64_t lda, const u
 
 // e4m3 x e4m3 -> bf16: C = (A * 2^(sa - 127)) (B * 2^(sb - 127))^T [+ bias], the ping-pong kernel at ES = 1.
 extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb,
-                                       const uint8_t* sb, void* C, int64_t ldc, const float* bias, void* aux, int64_t M, int64_t N,
-                                       int64_t K, int32_t epilogue, void* stream) {
+                                       const uint8_t* sb, void* C, int64_t ldc, const float* bias, void* aux, uint8_t* cq, uint8_t* cq_scale,
+                                       int64_t M, int64_t N, int64_t K, int32_t epilogue, void* stream) {
     VIPANT_REQUIRE(M > 0 && N > 0 && K > 0, VIPANT_EBADSHAPE, "gemm_nt_e4m3: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     VIPANT_REQUIRE(K % 128 == 0 && K >= 256 && N % 8 == 0, VIPANT_EBADSHAPE,
                    "gemm_nt_e4m3: need K %% 128 == 0, K >= 256 and N %% 8 == 0 (K=%ld N=%ld)", (long)K, (long)N);
@@ -1227,11 +1282,18 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
                    "gemm_nt_e4m3: bad leading dims lda=%ld ldb=%ld ldc=%ld", (long)lda, (long)ldb, (long)ldc);
     VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), VIPANT_EALIGN,
                    "gemm_nt_e4m3: operands must be 16-byte aligned");
-    VIPANT_REQUIRE(sa != nullptr && sb != nullptr, VIPANT_EBADSHAPE, "gemm_nt_e4m3: the row scales of both operands are required");
+    VIPANT_REQUIRE(sa != nullptr && sb != nullptr && (uintptr_t)sa % 8 == 0, VIPANT_EBADSHAPE,
+                   "gemm_nt_e4m3: the block scales of A (8-byte aligned) and the row scales of B are required");
+    VIPANT_REQUIRE((cq == nullptr) == (cq_scale == nullptr), VIPANT_EBADSHAPE, "gemm_nt_e4m3: cq and cq_scale go together");
+    VIPANT_REQUIRE(cq == nullptr || (N % 128 == 0 && (uintptr_t)cq % 16 == 0 && epilogue != VIPANT_EPI_BF16), VIPANT_EBADSHAPE,
+                   "gemm_nt_e4m3: the e4m3 form of the result needs N %% 128 == 0, a 16-byte aligned cq and one of the QuickGELU epilogues");
+    VIPANT_REQUIRE(C != nullptr || (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8), VIPANT_EBADSHAPE,
+                   "gemm_nt_e4m3: C may be NULL only when the QuickGELU epilogue leaves the e4m3 form alone");
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
     const char* var = getenv("VIPANT_GEMM_VARIANT");       // read per call, as in vipant_gemm_nt
     const int fp8_dbg = var ? atoi(var) : 0;
     GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, fp8_dbg & 4194304, sa, sb, 0, nullptr};
+    p.cq = cq; p.cqs = cq_scale;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case VIPANT_EPI_BF16:
@@ -1240,8 +1302,11 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
             return launch_pp_variant<VIPANT_EPI_BF16, 0, 1>(p, s);
         case VIPANT_EPI_QUICKGELU_D8:
         case VIPANT_EPI_DQUICKGELU_D8:
-            VIPANT_REQUIRE(aux != nullptr && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
+            VIPANT_REQUIRE((aux != nullptr || (C == nullptr && cq != nullptr)) && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
                            "gemm_nt_e4m3: the 8-bit QuickGELU' epilogues need a 16-byte aligned aux (the code matrix)");
+            if (cq != nullptr)
+                return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, true>(p, s)
+                                                            : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1, true>(p, s);
             return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1>(p, s)
                                                         : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1>(p, s);
         default:

@@ -25,34 +25,20 @@ __device__ __forceinline__ void store_stream4(f16_t* p, f32x4 v) {
     *(f16x4*)p = h;
 }
 
-// Row quantiser of vipant_quant_e4m3_rows (elementwise.hip) on a row that is already in registers, four consecutive elements per
-// lane and 256-column step: the values are first rounded to bf16, so the bytes and the scale are those the stand-alone kernel
-// produces from the bf16 tensor this kernel also writes.
+// The block quantiser of vipant_quant_e4m3_mx (elementwise.hip; MX layout: common.h) on a row that is already in registers, four
+// consecutive elements per lane and 256-column step -- a block of 32 is eight lanes: the values are first rounded to bf16, so bytes
+// and scales are those the stand-alone kernel produces from the bf16 tensor this kernel also writes.
 template <int NV>
-__device__ __forceinline__ void quant_row_e4m3(f32x4 (&o)[NV], uint8_t* __restrict__ qrow, uint8_t* __restrict__ qscale, int lane) {
-    float amax = 0.f;
+__device__ __forceinline__ void quant_row_mx(f32x4 (&o)[NV], uint8_t* __restrict__ qrow, uint8_t* __restrict__ scales, int64_t row, int lane) {
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const bf16x4 b = f32x4_to_bf16x4(o[t]);
-        o[t] = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[t][0]), fabsf(o[t][1])), fmaxf(fabsf(o[t][2]), fabsf(o[t][3]))));
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
-    int e = 0;
-    if (amax > 0.f) {
-        e = (int)((__float_as_uint(amax) >> 23) & 255u) - 127 - 8;
-        if (amax * __uint_as_float((uint32_t)(127 - e) << 23) > 448.f) e += 1;
-        e = e < -127 ? -127 : (e > 127 ? 127 : e);
-    }
-    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
-    if (lane == 0) *qscale = (uint8_t)(e + 127);
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        int w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[t][0] * inv, o[t][1] * inv, w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(o[t][2] * inv, o[t][3] * inv, w, true);
-        *(int*)(qrow + (t * 64 + lane) * 4) = w;
+        const f32x4 v = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+        const float amax = mx_lane_max<8>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        float inv;
+        const int e = mx_exponent(amax, &inv);
+        *(int*)(qrow + (t * 64 + lane) * 4) = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+        if ((lane & 7) == 0) scales[mx_scale_offset(row, t * 8 + (lane >> 3), NV * 2)] = (uint8_t)(e + 127);
     }
 }
 
@@ -105,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
             if (y32 != nullptr) *(f32x4*)(y32 + off) = o;
             v[t] = o;
         }
-        if (q8 != nullptr) quant_row_e4m3<NV>(v, q8 + row * D, q8s + row, lane);
+        if (q8 != nullptr) quant_row_mx<NV>(v, q8 + row * D, q8s, row, lane);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -180,7 +166,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const void* __restrict
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
             g[t] = o;
         }
-        if (q8 != nullptr) quant_row_e4m3<NV>(g, q8 + row * D, q8s + row, lane);
+        if (q8 != nullptr) quant_row_mx<NV>(g, q8 + row * D, q8s, row, lane);
     };
     // a ring of RING rows per wave: row r + (RING - 1) nwaves is requested before row r is reduced (static indices: the loop
     // body is written out RING times)

@@ -109,16 +109,40 @@ def quant_e4m3(x: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor = No
     return q, scale
 
 
-def gemm_nt_e4m3(a, sa, b, sb, c: torch.Tensor, *, bias=None, aux=None, epi: int = EPI_BF16):
-    """c[M,N] (bf16) = dequant(a, sa) @ dequant(b, sb)^T with the epilogue `epi`: e4m3 operands, row scales from quant_e4m3."""
+def quant_e4m3_mx(x: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor = None):
+    """bf16 rows [M, K] -> (e4m3 bytes [M, K], E8M0 BLOCK scales, one per 32 elements of a row, in the library's MX layout:
+    vipant_quant_e4m3_mx) -- the form an activation operand of gemm_nt_e4m3 takes."""
+    _need(x, BF16, "quant_e4m3_mx.x")
+    M, K = x.shape
+    if q is None:
+        q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((query("vipant_mx_scale_bytes", M, K),), dtype=torch.uint8, device=x.device)
+    call("vipant_quant_e4m3_mx", x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), M, K, _stream())
+    return q, scale
+
+
+def mx_scale_index(M: int, K: int, device) -> torch.Tensor:
+    """int64 [M, K // 32]: where the MX layout keeps the scale byte of (row, 32-element block) -- for tests and tools."""
+    m = torch.arange(M, device=device).view(M, 1)
+    kb = torch.arange(K // 32, device=device).view(1, K // 32)
+    return (((m >> 7) * (K // 128) + (kb >> 2)) * 16 + (m & 15)) * 32 + (kb & 3) * 8 + ((m >> 4) & 7)
+
+
+def gemm_nt_e4m3(a, sa, b, sb, c: Optional[torch.Tensor], *, bias=None, aux=None, epi: int = EPI_BF16, emit=None):
+    """c[M,N] (bf16) = dequant(a, sa) @ dequant(b, sb)^T with the epilogue `epi`: e4m3 operands; sa: a's block scales (quant_e4m3_mx),
+    sb: b's row scales (quant_e4m3).  emit = (bytes [M, N], block scales): the epilogue also leaves the e4m3 form of its result there;
+    c (and aux) may then be None (QuickGELU epilogue)."""
     assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and sa.dtype == torch.uint8 and sb.dtype == torch.uint8
     M, K = a.shape
     N = b.shape[0]
-    assert b.shape[1] == K and tuple(c.shape) == (M, N) and sa.numel() == M and sb.numel() == N, (a.shape, b.shape, c.shape)
-    if aux is not None:
+    assert b.shape[1] == K and sa.numel() >= query("vipant_mx_scale_bytes", M, K) and sb.numel() == N, (a.shape, b.shape, sa.shape)
+    assert c is None or tuple(c.shape) == (M, N)
+    if aux is not None and c is not None:
         assert aux.stride(0) == c.stride(0)
-    call("vipant_gemm_nt_e4m3", a.data_ptr(), a.stride(0), sa.data_ptr(), b.data_ptr(), b.stride(0), sb.data_ptr(), c.data_ptr(),
-         c.stride(0), _ptr(bias), _ptr(aux), M, N, K, epi, _stream())
+    call("vipant_gemm_nt_e4m3", a.data_ptr(), a.stride(0), sa.data_ptr(), b.data_ptr(), b.stride(0), sb.data_ptr(), _ptr(c),
+         c.stride(0) if c is not None else N, _ptr(bias), _ptr(aux), emit[0].data_ptr() if emit else None,
+         emit[1].data_ptr() if emit else None, M, N, K, epi, _stream())
     return c
 
 
@@ -291,13 +315,20 @@ def cast_weights(weights: Sequence[torch.Tensor], e4m3: bool = False):
     return wb, wt
 
 
-def fp8_plan(w=None, w2=None, act=None, dyq=None):
+def fp8_plan(w=None, w2=None, act=None, dyq=None, emit=None):
     """struct vipant_fp8_plan for one fused-operator call: w / w2 = (bytes, row scales) of the operator's weights, act = (scratch
-    bytes [M, 4D], scratch row scales [M]), dyq = (bytes [M, D], row scales [M]): the quantised stream gradient that travels
-    between the backward operators."""
+    bytes [M, 4D], its block scales), emit = the same pair for the e4m3 form an MLP operator's first contraction leaves for its
+    second, dyq = (bytes [M, D], block scales): the quantised stream gradient that travels between the backward operators."""
     from ._ffi import Fp8Plan
     return Fp8Plan(w[0].data_ptr(), w[1].data_ptr(), w2[0].data_ptr() if w2 else None, w2[1].data_ptr() if w2 else None,
-                   act[0].data_ptr(), act[1].data_ptr(), dyq[0].data_ptr() if dyq else None, dyq[1].data_ptr() if dyq else None)
+                   act[0].data_ptr(), act[1].data_ptr(), emit[0].data_ptr() if emit else None, emit[1].data_ptr() if emit else None,
+                   dyq[0].data_ptr() if dyq else None, dyq[1].data_ptr() if dyq else None)
+
+
+def fp8_scratch(M: int, D: int, device):
+    """(bytes [M, 4D], block scales) for an e4m3 activation operand of up to 4 D columns."""
+    return (torch.empty((M, 4 * D), dtype=torch.uint8, device=device),
+            torch.empty((query("vipant_mx_scale_bytes", M, 4 * D),), dtype=torch.uint8, device=device))
 
 
 _frozen_cache: Dict[tuple, tuple] = {}
@@ -577,18 +608,19 @@ class BackboneFn(torch.autograd.Function):
         if not train:   # frozen tower: one set of temporaries for all layers
             h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
             mean = torch.empty((M,), dtype=F32, device=dev); rstd = torch.empty((M,), dtype=F32, device=dev)
-        if not keep_mlp:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
+        fp8 = bool(fp8)
+        # (e4m3 towers that do not keep the MLP activations need neither: the c_fc epilogue leaves g's e4m3 form for c_proj and nothing else)
+        if not keep_mlp and not fp8:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
         y_prev = None
         ctx_alg = prune and LAST_BLOCK_CTX and H in (8, 12, 16) and S <= 1024
         # e4m3 operands in the NT contractions (configs[4]): a property of the tower, whether or not this call records a backward --
         # the no-grad feature pass of `running.micro_batch` and evaluation must see the forward the training pass differentiates
-        fp8 = bool(fp8)
         if train or fp8:        # bf16 copies (W and W^T) of the 4 L weight matrices: one launch per step
             mats = [params[12 * l + i] for l in range(L) for i in (2, 4, 8, 10)]
             if fp8:
                 wb_all, wt_all, wq_all, wtq_all = cast_weights(mats, e4m3=True)
-                act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev))
+                act, emit = fp8_scratch(M, D, dev), fp8_scratch(M, D, dev)
             else:
                 wb_all, wt_all = cast_weights(mats)
         for l in range(L):
@@ -678,10 +710,11 @@ class BackboneFn(torch.autograd.Function):
                 gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU_D8)
                 gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             else:
+                only_q = fp8 and not keep_mlp        # c_proj's operand is all that is wanted of g: neither g nor the codes are written
                 call("vipant_ln_mlp_quickgelu_fwd_e4m3", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
                      wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
-                     rstd2.data_ptr(), u.data_ptr(), g.data_ptr(), y2.data_ptr(), M, D,
-                     C.byref(fp8_plan(q_fc, q_pr, act)) if fp8 else None, sflags(x), st)
+                     rstd2.data_ptr(), None if only_q else u.data_ptr(), None if only_q else g.data_ptr(), y2.data_ptr(), M, D,
+                     C.byref(fp8_plan(q_fc, q_pr, act, emit=emit)) if fp8 else None, sflags(x), st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
@@ -746,11 +779,11 @@ class BackboneFn(torch.autograd.Function):
                 dx = None
                 dx_b = cast_bf16_flat(dx_in.contiguous())
         ws = scratch("block_bwd", query("vipant_block_workspace_bytes", M, D), dev)
-        act = dyq = None
+        act = emit = dyq = None
         if fp8:
-            act = (torch.empty((M, 4 * D), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.uint8, device=dev))
+            act, emit = fp8_scratch(M, D, dev), fp8_scratch(M, D, dev)
             if not prune:
-                dyq = quant_e4m3(dx_b)      # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
+                dyq = quant_e4m3_mx(dx_b)   # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
         du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
         dh = torch.empty((M, D), dtype=BF16, device=dev)
         do = torch.empty((M, D), dtype=BF16, device=dev)
@@ -821,7 +854,7 @@ class BackboneFn(torch.autograd.Function):
                     dx = torch.empty((M, D), dtype=F32, device=dev)
                     call("vipant_cast_f32", dx_b.data_ptr(), dx.data_ptr(), M * D, st)
                 if fp8:
-                    dyq = quant_e4m3(dx_b)
+                    dyq = quant_e4m3_mx(dx_b)
                 for i, v in enumerate(lg.views):
                     grads[12 * l + i] = v
                 if ctx.grad_sync is not None:
@@ -840,7 +873,7 @@ class BackboneFn(torch.autograd.Function):
                  h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq, emit=emit)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
