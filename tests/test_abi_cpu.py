@@ -60,9 +60,14 @@ def test_bad_arguments_are_reported_not_executed():
     with pytest.raises(_ffi.VipantError, match="workspace"):
         _ffi.call("vipant_infonce_fwd_bwd", 16, 16, 16, 0.0, 16, None, None, None, 1.0, 64, 512, 0, 64, None, 0, None)
     with pytest.raises(_ffi.VipantError, match="K % 128"):
-        _ffi.call("vipant_gemm_nt_e4m3", 16, 192, 16, 16, 192, 16, 16, 64, None, None, 4, 64, 192, 0, None)
-    with pytest.raises(_ffi.VipantError, match="row scales"):
-        _ffi.call("vipant_gemm_nt_e4m3", 16, 256, None, 16, 256, 16, 16, 64, None, None, 4, 64, 256, 0, None)
+        _ffi.call("vipant_gemm_nt_e4m3", 16, 192, 16, 16, 192, 16, 16, 64, None, None, None, None, 4, 64, 192, 0, None)
+    with pytest.raises(_ffi.VipantError, match="block scales of A"):
+        _ffi.call("vipant_gemm_nt_e4m3", 16, 256, None, 16, 256, 16, 16, 64, None, None, None, None, 4, 64, 256, 0, None)
+    with pytest.raises(_ffi.VipantError, match="go together"):
+        _ffi.call("vipant_gemm_nt_e4m3", 16, 256, 16, 16, 256, 16, 16, 64, None, None, 16, None, 4, 64, 256, 0, None)
+    with pytest.raises(_ffi.VipantError, match="K % 128"):
+        _ffi.call("vipant_quant_e4m3_mx", 16, 192, 16, 192, 16, 4, 192, None)
+    assert _ffi.query("vipant_mx_scale_bytes", 323584, 4096) == 323584 * 4096 // 32 and _ffi.query("vipant_mx_scale_bytes", 130, 256) == 2 * 2 * 512
     with pytest.raises(_ffi.VipantError, match="K <= 8192"):
         _ffi.call("vipant_quant_e4m3_rows", 16, 16384, 16, 16384, 16, 4, 16384, None)
     with pytest.raises(_ffi.VipantError, match="go together"):
