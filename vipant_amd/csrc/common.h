@@ -144,6 +144,45 @@ __device__ __forceinline__ int mx_pack4(float a, float b, float c, float d) {
     w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
     return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
 }
+// The same quantiser on values that ARE bf16 (every producer rounds to bf16 first), in integer / packed arithmetic -- the two-output
+// epilogues are bound by their own VALU work: |x| as a 15-bit integer orders like the value, so the block maximum is an AND and a
+// packed 16-bit max per two elements; the exponent comes from its bit fields (amax / 2^e in [256, 512): above 448 exactly when the
+// 7-bit mantissa exceeds 0x60); v_cvt_scalef32_pk_fp8_bf16 divides two bf16 by the scale and rounds to e4m3 in one instruction.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mx_absmax2(uint32_t acc, uint32_t two_bf16) {       // packed max of |.| over two more elements
+    const uint32_t a = two_bf16 & 0x7FFF7FFFu;
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, acc), __builtin_bit_cast(u16x2, a)));
+}
+template <int NL>
+__device__ __forceinline__ uint32_t mx_lane_max_u(uint32_t v) {
+#define VIPANT_MAXU(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xF, 0xF, false))
+    VIPANT_MAXU(0xB1);
+    if (NL >= 4) VIPANT_MAXU(0x4E);
+#undef VIPANT_MAXU
+    if (NL == 8) v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
+    return v;
+}
+// packed |.| maxima of a lane -> the block's scale byte (E8M0) over NL lanes, and the float 2^e the conversion divides by
+template <int NL>
+__device__ __forceinline__ uint32_t mx_scale_byte(uint32_t packed_max, float* scale) {
+    uint32_t m = max(packed_max & 0xFFFFu, packed_max >> 16);
+    m = mx_lane_max_u<NL>(m);
+    int e = 0;
+    if (m != 0u) {
+        e = (int)(m >> 7) - 127 - 8 + ((m & 0x7Fu) > 0x60u ? 1 : 0);
+        e = e < -127 ? -127 : e;                    // (a bf16 below 2^127 never needs e > 119)
+    }
+    const uint32_t byte = (uint32_t)(e + 127);
+    *scale = __uint_as_float(byte ? byte << 23 : 0x00400000u);          // 2^e (2^-127 is a subnormal)
+    return byte;
+}
+__device__ __forceinline__ int mx_pack4_bf16(uint32_t lo2, uint32_t hi2, float scale) {      // four bf16 (two packed words) -> four e4m3 bytes
+    s16x2 w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, lo2), scale, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, hi2), scale, true);
+    return __builtin_bit_cast(int, w);
+}
 
 namespace tickets {
 __device__ __forceinline__ uint32_t take(uint32_t* p, uint32_t n = 1u) {

@@ -432,15 +432,10 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __rest
         if (c >= total) break;
         const int64_t row = c / cpr;
         const int col = (int)(c - row * cpr) * 8;
-        const bf16x8 v = *(const bf16x8*)(x + row * ldx + col);
-        float amax = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
-        amax = mx_lane_max<4>(amax);
-        float inv;
-        const int e = mx_exponent(amax, &inv);
-        *(int2*)(q + row * ldq + col) = int2{mx_pack4((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
-                                             mx_pack4((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
+        const u32x4 w = *(const u32x4*)(x + row * ldx + col);                // eight bf16
+        float sc;
+        const uint32_t e = mx_scale_byte<4>(mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), w[2]), w[3]), &sc) - 127u;
+        *(int2*)(q + row * ldq + col) = int2{mx_pack4_bf16(w[0], w[1], sc), mx_pack4_bf16(w[2], w[3], sc)};
         if ((threadIdx.x & 3) == 0) scale[mx_scale_offset(row, col >> 5, K >> 7)] = (uint8_t)(e + 127);
     }
 }

@@ -394,22 +394,20 @@ __device__ __forceinline__ void load_codes(const GemmNT& p, int m0, int n0, int 
 
 // `pre`: the codes of round 0, requested by the caller during the tile's last K-tile (QuickGELU' launch on the DEEP schedule: the
 // HBM round trip of the first round's codes is then off the epilogue's critical path), or NULL
-template <int EPI, bool EMIT = false>
+// EMIT: 0 = the bf16 result only; 1 = also its e4m3 form (p.cq, p.cqs); 2 = the e4m3 form ALONE (QuickGELU epilogue of a tower that
+// keeps neither g nor the derivative codes: their arithmetic is not compiled in)
+template <int EPI, int EMIT = 0>
 __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], const f32x4 (&bv)[4], char* stg, char* stg_hi,
                                             int m0, int n0, int grp, int wl, int frow, int fq, int tid,
                                             const u32x2 (*pre)[4] = nullptr) {
     // EMIT: 8 consecutive bf16 results of row m from column n on (n % 8 == 0; the four threads of a 32-column block are four
     // consecutive lanes, all inside the bounds together since N % 32 == 0) -> e4m3 bytes + the block's scale (MX layout, common.h)
     auto emit8 = [&](const bf16x8& val, int m, int n, int ch) {
-        float f[8], amax = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { f[e] = (float)val[e]; amax = fmaxf(amax, fabsf(f[e])); }
-        amax = mx_lane_max<4>(amax);
-        float inv;
-        const int ex = mx_exponent(amax, &inv);
-        *(int2*)(p.cq + (int64_t)m * p.N + n) = int2{mx_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
-                                                      mx_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv)};
-        if ((ch & 3) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)(ex + 127);
+        const u32x4 w = __builtin_bit_cast(u32x4, val);
+        float sc;
+        const uint32_t byte = mx_scale_byte<4>(mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), w[2]), w[3]), &sc);
+        *(int2*)(p.cq + (int64_t)m * p.N + n) = int2{mx_pack4_bf16(w[0], w[1], sc), mx_pack4_bf16(w[2], w[3], sc)};
+        if ((ch & 3) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)byte;
     };
     // rows 0-15 of a round are staged at `stg`, rows 16-31 at `stg_hi` (the ring kernel has two free 8-KiB pieces, not one of 16)
     stg_hi -= 16 * 512;
@@ -489,28 +487,27 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                             const f32x2 b = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
                             const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
                             const f32x2 ge = u * sg;
-                            const f32x2 c = (ge * 361.675f) * (1.0f - sg) + (sg * 212.5f + 21.25f);
                             g[e] = (bf16_t)ge[0];
                             g[e + 1] = (bf16_t)ge[1];
-                            uint32_t& w = cw[h * 2 + (e >> 2)];
-                            w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
-                            w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
+                            if (EMIT != 2) {
+                                const f32x2 c = (ge * 361.675f) * (1.0f - sg) + (sg * 212.5f + 21.25f);
+                                uint32_t& w = cw[h * 2 + (e >> 2)];
+                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[0], (uint32_t)(e & 3), w);
+                                w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
+                            }
                         }
-                        if (!EMIT || p.C != nullptr) *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
+                        if (EMIT != 2) *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
                     }
-                    if (!EMIT || p.aux != nullptr) *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
+                    if (EMIT != 2) *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
                     if (EMIT) {         // 16 columns per thread: two threads per 32-column block
-                        float f[16], amax = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) { f[e] = (float)g2[e >> 3][e & 7]; amax = fmaxf(amax, fabsf(f[e])); }
-                        amax = mx_lane_max<2>(amax);
-                        float inv;
-                        const int ex = mx_exponent(amax, &inv);
-                        *(i32x4*)(p.cq + (int64_t)m * p.N + n) = i32x4{mx_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
-                                                    mx_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv),
-                                                    mx_pack4(f[8] * inv, f[9] * inv, f[10] * inv, f[11] * inv),
-                                                    mx_pack4(f[12] * inv, f[13] * inv, f[14] * inv, f[15] * inv)};
-                        if ((cp & 1) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)(ex + 127);
+                        const u32x4 w0 = __builtin_bit_cast(u32x4, g2[0]), w1 = __builtin_bit_cast(u32x4, g2[1]);
+                        uint32_t mx = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w0[0]), w0[1]), w0[2]), w0[3]);
+                        mx = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(mx, w1[0]), w1[1]), w1[2]), w1[3]);
+                        float sc;
+                        const uint32_t byte = mx_scale_byte<2>(mx, &sc);
+                        *(i32x4*)(p.cq + (int64_t)m * p.N + n) = i32x4{mx_pack4_bf16(w0[0], w0[1], sc), mx_pack4_bf16(w0[2], w0[3], sc),
+                                                                       mx_pack4_bf16(w1[0], w1[1], sc), mx_pack4_bf16(w1[2], w1[3], sc)};
+                        if ((cp & 1) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)byte;
                     }
                 }
             }
@@ -538,13 +535,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                         g[e] = (bf16_t)(u * sg);
                         code[e] = gelu_code(sg * (1.0f + 1.702f * u * (1.0f - sg)));
                     }
-                    if (EMIT && p.aux == nullptr) {
+                    if (EMIT == 2) {
                     } else if (D8)
                         *(u32x2*)((uint8_t*)p.aux + o) = u32x2{code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24,
                                                                code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
                     else
                         *(bf16x8*)((bf16_t*)p.aux + o) = v;
-                    if (!EMIT || p.C != nullptr) *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    if (EMIT != 2) *(bf16x8*)((bf16_t*)p.C + o) = g;
                     if (EMIT) emit8(g, m, n, ch);
                 } else {  // QuickGELU'
                     bf16x8 d;
@@ -584,7 +581,7 @@ template <int V> struct Int { static constexpr int value = V; };
 // ES = bytes per operand element: 2 = bf16 (K-tile of 64), 1 = e4m3 with per-row power-of-two scales (K-tile of 128: the same
 // 128-byte rows, the same LDS images, DMA stream and barrier schedule; half the MFMA instructions, each twice as long, for
 // twice the K -- twice the FLOP per byte moved and per cycle).
-template <int EPI, int VAR, int ES = 2, bool EMIT = false>
+template <int EPI, int VAR, int ES = 2, int EMIT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -963,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
 }
 
-template <int EPI, int VAR, int ES = 2, bool EMIT = false>
+template <int EPI, int VAR, int ES = 2, int EMIT = 0>
 int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     static DeviceOnce once;
     if (first_on_device(once)) {
@@ -1304,9 +1301,15 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
         case VIPANT_EPI_DQUICKGELU_D8:
             VIPANT_REQUIRE((aux != nullptr || (C == nullptr && cq != nullptr)) && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
                            "gemm_nt_e4m3: the 8-bit QuickGELU' epilogues need a 16-byte aligned aux (the code matrix)");
+            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && (C == nullptr) != (aux == nullptr)) {
+                vipant_set_error("gemm_nt_e4m3: with cq, C and aux are both given or both NULL");
+                return VIPANT_EBADSHAPE;
+            }
+            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C == nullptr)
+                return launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 2>(p, s);           // the e4m3 form alone
             if (cq != nullptr)
-                return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, true>(p, s)
-                                                            : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1, true>(p, s);
+                return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 1>(p, s)
+                                                            : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1, 1>(p, s);
             return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1>(p, s)
                                                         : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1>(p, s);
         default:

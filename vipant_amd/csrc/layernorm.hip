@@ -6,6 +6,7 @@
 
 #include "common.h"
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr float LN_EPS = 1e-5f;
@@ -33,11 +34,10 @@ __device__ __forceinline__ void quant_row_mx(f32x4 (&o)[NV], uint8_t* __restrict
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
         const bf16x4 b = f32x4_to_bf16x4(o[t]);
-        const f32x4 v = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-        const float amax = mx_lane_max<8>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        float inv;
-        const int e = mx_exponent(amax, &inv);
-        *(int*)(qrow + (t * 64 + lane) * 4) = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+        const u32x2 w = __builtin_bit_cast(u32x2, b);
+        float sc;
+        const int e = (int)mx_scale_byte<8>(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), &sc) - 127;
+        *(int*)(qrow + (t * 64 + lane) * 4) = mx_pack4_bf16(w[0], w[1], sc);
         if ((lane & 7) == 0) scales[mx_scale_offset(row, t * 8 + (lane >> 3), NV * 2)] = (uint8_t)(e + 127);
     }
 }
