@@ -449,6 +449,7 @@ def main():
         torch.cuda.synchronize()
         out["infonce_alone"]["ms_rank_strip_512_of_4096"] = round(e0.elapsed_time(e1) / 10, 4)
         out["infonce_alone"]["workspace_mb"] = round(_ffi.query("vipant_infonce_workspace_bytes", Bn, E) / 1e6, 1)
+        out["infonce_alone"]["workspace_mb_rank_strip"] = round(_ffi.query("vipant_infonce_strip_workspace_bytes", Bn, E, 512) / 1e6, 1)
         if world == 1 and lbr and not args.no_full_last_block_check:
             # transparency: the same build, same box, with the towers' last block evaluated on EVERY token (what the reference
             # computes before its read-out discards all rows but one) -- a short untimed-region extra, never `value`

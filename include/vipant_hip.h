@@ -263,8 +263,12 @@ int32_t vipant_scatter_rows(const float* g, const int64_t* idx, float* dx, int64
  * dx1, dx2 fp32 [nrows, E], scaled by grad_scale; dlogit_scale is the full-batch value * grad_scale.
  * Any of dx1 / dx2 / dlogit_scale may be NULL (forward only).  E % 64 == 0.  Up to 768 clips at E = 512 the call is three
  * launches of row-block kernels (no B x B operand in HBM but the fp32 logits themselves, 2 B^2 floats); above, 256 x 256 tile
- * kernels whose s.dZ makes a bf16 round trip.  Same results within the rounding of the bf16 gradient operands. */
+ * kernels whose s.dZ makes a bf16 round trip.  Same results within the rounding of the bf16 gradient operands.
+ * Strip form (round 5; B > 768, 0 < nrows <= 768, E = 512 -- one rank of an N-GPU step): pass 1 keeps the fp32-grade logits of the
+ * strip's rows of Z and of Z^T (2 nrows B floats), one launch forms the strip's gradients from them; nothing B x B is stored, and
+ * vipant_infonce_strip_workspace_bytes(B, E, nrows) (55 MB at B = 4096 / 512 rows against 181 MB) is enough workspace. */
 size_t vipant_infonce_workspace_bytes(int64_t B, int64_t E);
+size_t vipant_infonce_strip_workspace_bytes(int64_t B, int64_t E, int64_t nrows);
 int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, const float* logit_scale, float scale_max,
                                float* loss, float* dx1, float* dx2, float* dlogit_scale, float grad_scale,
                                int64_t B, int64_t E, int64_t row0, int64_t nrows, void* workspace,

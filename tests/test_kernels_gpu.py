@@ -649,6 +649,9 @@ def test_infonce_golden(ops, golden, nce_path, B, tag):
 
 @pytest.mark.parametrize("B,row0,nrows", [(512, 0, 512), (768, 512, 256), (769, 0, 769), (1000, 0, 1000), (1024, 256, 256), (4096, 3584, 512),
                                           (8192, 7168, 1024),                      # BASELINE.json configs[4]: 8 x 1024 clips
+                                          # round 5, the strip path (B > 768, a strip of <= 768 rows: one rank of an N-GPU step; the two
+                                          # cases above with 256 / 512 rows take it too): first / odd-start / maximal strips
+                                          (4096, 0, 512), (2000, 1000, 500), (1025, 1, 768), (8192, 4096, 512),
                                           (432, 108, 108), (432, 324, 108), (8, 4, 4), (30, 3, 5)])      # strips off the 8-row grid
 def test_infonce_large_and_sliced(ops, nce_path, B, row0, nrows):
     from oracle import ref_cpu as R

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "vipant_scatter_rows": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_scatter_rows_bf16": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "vipant_infonce_workspace_bytes": (_sz, [_i64, _i64]),
+    "vipant_infonce_strip_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vipant_infonce_fwd_bwd": (_i32, [_p, _p, _p, _f32, _p, _p, _p, _p, _f32, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "vipant_retrieval_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "vipant_retrieval_ranks": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _sz, _p]),

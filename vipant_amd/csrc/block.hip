@@ -180,8 +180,10 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd(const float* x, const uint16_t* a
 extern "C" int32_t vipant_mlp_quickgelu_recompute_e4m3(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,
                                                        uint16_t* g, int64_t M, int64_t D, const vipant_fp8_plan* plan,
                                                        void* stream) {
-    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D,
-              D, VIPANT_EPI_QUICKGELU_D8, stream);
+    // h == NULL with a plan: the plan's act_q / act_scale already hold h's e4m3 form (kept from the forward's LayerNorm pass)
+    const bool kept = plan != nullptr && h == nullptr;
+    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, kept ? plan->act_q : nullptr,
+              kept ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream);
 }
 
 extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,

@@ -35,12 +35,17 @@ struct NceWs {       // carved out of the caller's workspace; all offsets 256-B 
     bf16_t *x1t, *x2t;
     float *zws, *pmax, *psum, *pwz, *accum;
     int Bp32, Bp128, KC;
+    // the strip path (B > ROWS_MAX_B, gradients for a strip of <= ROWS_MAX_B rows: what one rank of an N-GPU step asks for): pass 1
+    // leaves the fp32-grade logits of the strip's rows of Z (zrow [nrows][Bp128]) and of Z^T (zcol [nrows][Bp128]) as it passes them
+    float *zrow, *zcol;
+    int zrow0, znrows;
 };
 constexpr int ROWS_MAX_B = 768, ROWS_E = 512;      // 54 us against 114 at B = 512; at B = 1024 the tile kernels win (117 against 135)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-NceWs carve(char* base, int64_t B, int64_t E) {
+// strip_rows > 0: the layout of the strip path (no B x B gradient matrices, no split-reduction partials)
+NceWs carve(char* base, int64_t B, int64_t E, int64_t strip_rows = 0) {
     NceWs w;
     const int64_t Bp = (B + 63) / 64 * 64;
     const int ntm = (int)ceil_div(B, BM), ntn = (int)ceil_div(B, BN);
@@ -49,8 +54,8 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     auto take = [&](size_t bytes) { char* p = base + off; off += align256(bytes); return p; };
     w.x1cat = (bf16_t*)take((size_t)B * 3 * E * 2);
     w.x2cat = (bf16_t*)take((size_t)B * 3 * E * 2);
-    w.dz = (bf16_t*)take((size_t)B * Bp * 2);
-    w.dzt = (bf16_t*)take((size_t)B * Bp * 2);
+    w.dz = (bf16_t*)take(strip_rows ? 0 : (size_t)B * Bp * 2);
+    w.dzt = (bf16_t*)take(strip_rows ? 0 : (size_t)B * Bp * 2);
     w.rmax = (float*)take((size_t)w.rparts * B * 4); w.rsum = (float*)take((size_t)w.rparts * B * 4);
     w.rwz = (float*)take((size_t)w.rparts * B * 4);
     w.cmax = (float*)take((size_t)w.cparts * B * 4); w.csum = (float*)take((size_t)w.cparts * B * 4);
@@ -58,20 +63,28 @@ NceWs carve(char* base, int64_t B, int64_t E) {
     w.diag = (float*)take((size_t)B * 4); w.rlse = (float*)take((size_t)B * 4); w.clse = (float*)take((size_t)B * 4);
     w.scal = (float*)take(256);
     w.part = (float*)take((size_t)ceil_div(B, 16) * 2 * 4);
-    w.dxtmp = (float*)take((size_t)(B + 8) * E * 4);          // gradient rows of a strip that does not start on a multiple of 8
-    w.dxtmp2 = (float*)take((size_t)(B + 8) * E * 4);
-    w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
-    const size_t pair_bytes = vipant_gemm_tn_pair_workspace_bytes(B, B, E);
-    if (pair_bytes > w.tn_bytes) w.tn_bytes = pair_bytes;
+    w.dxtmp = (float*)take(strip_rows ? 0 : (size_t)(B + 8) * E * 4);          // gradient rows of a strip that does not start on a multiple of 8
+    w.dxtmp2 = (float*)take(strip_rows ? 0 : (size_t)(B + 8) * E * 4);
+    w.tn_bytes = 0;
+    if (!strip_rows) {
+        w.tn_bytes = vipant_gemm_tn_workspace_bytes(B, B, E);
+        const size_t pair_bytes = vipant_gemm_tn_pair_workspace_bytes(B, B, E);
+        if (pair_bytes > w.tn_bytes) w.tn_bytes = pair_bytes;
+    }
     w.tn_ws = take(w.tn_bytes);
     w.Bp32 = (int)((B + 31) / 32 * 32); w.Bp128 = (int)((B + 127) / 128 * 128); w.KC = w.Bp128 / 128;
-    const bool rows = B <= ROWS_MAX_B && E == ROWS_E;
+    const bool rows = (B <= ROWS_MAX_B || strip_rows) && E == ROWS_E;
     w.x1t = (bf16_t*)take(rows ? (size_t)E * w.Bp32 * 2 : 0);
     w.x2t = (bf16_t*)take(rows ? (size_t)E * w.Bp32 * 2 : 0);
-    w.zws = (float*)take(rows ? (size_t)2 * B * w.Bp128 * 4 : 0);
-    w.pmax = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
-    w.psum = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
-    w.pwz = (float*)take(rows ? (size_t)2 * w.KC * B * 4 : 0);
+    w.zrow = (float*)take((size_t)strip_rows * w.Bp128 * 4);
+    w.zcol = (float*)take((size_t)strip_rows * w.Bp128 * 4);
+    if (!strip_rows) w.zrow = w.zcol = nullptr;
+    w.zrow0 = 0; w.znrows = 0;
+    const bool small = B <= ROWS_MAX_B && E == ROWS_E;
+    w.zws = (float*)take(small ? (size_t)2 * B * w.Bp128 * 4 : 0);
+    w.pmax = (float*)take(small ? (size_t)2 * w.KC * B * 4 : 0);
+    w.psum = (float*)take(small ? (size_t)2 * w.KC * B * 4 : 0);
+    w.pwz = (float*)take(small ? (size_t)2 * w.KC * B * 4 : 0);
     w.accum = (float*)take(256);
     w.total = off;
     return w;
@@ -151,6 +164,33 @@ __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K,
                     acc[i][j][r] = z;
                     if (m == n && m < B) w.diag[m] = z;
                 }
+        if (w.zrow != nullptr) {        // strip path: the logits of the strip's rows of Z, and of its rows of Z^T, stay in HBM for the gradient kernel
+            const int r0 = w.zrow0, r1 = w.zrow0 + w.znrows;
+            if (m0 < r1 && m0 + BM > r0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = mb + i * 16;
+                    if (m >= r0 && m < r1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (nb + j * 16 < w.Bp128) *(f32x4*)(w.zrow + (int64_t)(m - r0) * w.Bp128 + nb + j * 16) = acc[i][j];
+                    }
+                }
+            }
+            if (n0 < r1 && n0 + BN > r0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = nb + j * 16 + r;
+                        if (n >= r0 && n < r1) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                if (mb + i * 16 < w.Bp128) w.zcol[(int64_t)(n - r0) * w.Bp128 + mb + i * 16] = acc[i][j][r];
+                        }
+                    }
+            }
+        }
         // rows: over this wave's 64 columns
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -534,9 +574,68 @@ __global__ __launch_bounds__(256) void nce_rows_grad_kernel(NceWs w, int B, floa
     }
 }
 
+// The gradient kernel of the strip path: nce_rows_grad_kernel's product for the rows [row0, row0 + nrows) of a LARGE batch -- the
+// strip's fp32-grade logits come from pass 1 (zrow / zcol), the log-sum-exp vectors from the merge kernel, so that nothing B x B is
+// stored and no split reduction follows: dx1[m] = sum_n s dZ[m, n] x2[n] (side 0, keys n) and dx2[m] = sum_n s dZ[n, m] x1[n] (side 1).
+template <int E, int CPW>
+__global__ __launch_bounds__(256) void nce_strip_grad_kernel(NceWs w, int B, float* __restrict__ dx1, float* __restrict__ dx2, int row0,
+                                                             int nrows, float gscale) {
+    extern __shared__ float lse_o[];            // log-sum-exp of the OTHER side, per key: B floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+    const int blk = blockIdx.x, side = blockIdx.y, col0 = blockIdx.z * (64 * CPW) + 16 * CPW * wave;
+    float* dx = side == 0 ? dx1 : dx2;
+    if (dx == nullptr) return;
+    const float* lo = side == 0 ? w.clse : w.rlse;
+    const float* lq_all = side == 0 ? w.rlse : w.clse;
+    for (int n = threadIdx.x; n < B; n += 256) lse_o[n] = lo[n];
+    __syncthreads();
+    const int ml = 16 * blk + r;                 // row inside the strip
+    const int m = row0 + ml;
+    const bool live = ml < nrows;
+    const float lq = lq_all[live ? m : row0];
+    const float s = w.scal[0], kf = gscale / (float)B * s;
+    const float* zrow = (side == 0 ? w.zrow : w.zcol) + (int64_t)(live ? ml : 0) * w.Bp128 + 8 * g;
+    const bf16_t* xt = (side == 0 ? w.x2t : w.x1t) + (int64_t)(col0 + r) * w.Bp32 + 8 * g;       // rows = this wave's columns
+    f32x4 acc[CPW];
+#pragma unroll
+    for (int ct = 0; ct < CPW; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = w.Bp32 / 32;
+#pragma unroll 4
+    for (int ks = 0; ks < nsteps; ++ks) {
+        const int k0 = 32 * ks;
+        bf16x8 xf[CPW];
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) xf[ct] = *(const bf16x8*)(xt + (int64_t)16 * ct * w.Bp32 + k0);
+        const f32x4 z0 = *(const f32x4*)(zrow + k0), z1 = *(const f32x4*)(zrow + k0 + 4);
+        bf16x8 bd;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = k0 + 8 * g + e;
+            const float z = e < 4 ? z0[e] : z1[e - 4];
+            float d = 0.f;
+            if (live && n < B) d = (__expf(z - lq) + __expf(z - lse_o[n]) - (m == n ? 2.f : 0.f)) * kf;
+            bd[e] = (bf16_t)d;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ct], bd, acc[ct], 0, 0, 0);
+    }
+    if (live) {
+        float* orow = dx + (int64_t)ml * E + col0 + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) *(f32x4*)(orow + 16 * ct) = acc[ct];
+    }
+}
+
+bool strip_path(int64_t B, int64_t E, int64_t nrows) { return B > ROWS_MAX_B && E == ROWS_E && nrows > 0 && nrows <= ROWS_MAX_B && nrows < B; }
+
 }  // namespace
 
 extern "C" size_t vipant_infonce_workspace_bytes(int64_t B, int64_t E) { return carve(nullptr, B, E).total; }
+// the workspace when gradients are wanted for `nrows` rows only (0 < nrows <= 768 of B > 768 rows, E = 512: the per-rank form of an
+// N-GPU step): no B x B gradient matrices, no split-reduction partials.  Other shapes: vipant_infonce_workspace_bytes.
+extern "C" size_t vipant_infonce_strip_workspace_bytes(int64_t B, int64_t E, int64_t nrows) {
+    return strip_path(B, E, nrows) ? carve(nullptr, B, E, nrows).total : carve(nullptr, B, E).total;
+}
 
 extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, const float* logit_scale, float scale_max,
                                           float* loss, float* dx1, float* dx2, float* dlogit_scale, float grad_scale,
@@ -545,11 +644,15 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     VIPANT_REQUIRE(B > 0 && E > 0 && E % 64 == 0, VIPANT_EBADSHAPE, "infonce: need E %% 64 == 0 (B=%ld E=%ld)", (long)B, (long)E);
     VIPANT_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= B, VIPANT_EBADSHAPE,
                    "infonce: bad row slice [%ld, %ld) of %ld", (long)row0, (long)(row0 + nrows), (long)B);
-    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= vipant_infonce_workspace_bytes(B, E), VIPANT_ENOWORKSPACE,
-                   "infonce: workspace too small");
+    const char* strip_env = getenv("VIPANT_NCE_STRIP");
+    const bool strip = strip_path(B, E, nrows) && (dx1 != nullptr || dx2 != nullptr) && !(strip_env && strip_env[0] == '0');
+    VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= (strip ? vipant_infonce_strip_workspace_bytes(B, E, nrows)
+                                                                      : vipant_infonce_workspace_bytes(B, E)),
+                   VIPANT_ENOWORKSPACE, "infonce: workspace too small");
     VIPANT_REQUIRE((uintptr_t)workspace % 256 == 0, VIPANT_EALIGN, "infonce: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const NceWs w = carve((char*)workspace, B, E);
+    NceWs w = carve((char*)workspace, B, E, strip ? nrows : 0);
+    if (strip) { w.zrow0 = (int)row0; w.znrows = (int)nrows; }
     static DeviceOnce once;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -562,7 +665,7 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     const char* rows_env = getenv("VIPANT_NCE_ROWS");
     const bool rows_path = B <= ROWS_MAX_B && E == ROWS_E && !(rows_env && rows_env[0] == '0');
     hipLaunchKernelGGL(nce_prep_kernel, dim3((unsigned)(pb > 2048 ? 2048 : pb)), dim3(256), 0, s, x1, x2, logit_scale,
-                       scale_max, w, (int)B, (int)E, rows_path ? 1 : 0);
+                       scale_max, w, (int)B, (int)E, (rows_path || strip) ? 1 : 0);
     VIPANT_LAUNCH_CHECK();
     if (rows_path) {
         // few clips (the step's own batch on one GPU): 256 x 256 tiles would leave this on 4-16 CUs for three dependent
@@ -584,6 +687,20 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     hipLaunchKernelGGL(nce_final_kernel, dim3(1), dim3(256), 0, s, w, (int)B, nparts, grad_scale, loss, dlogit_scale);
     VIPANT_LAUNCH_CHECK();
     if ((dx1 == nullptr && dx2 == nullptr) || nrows == 0) return VIPANT_OK;
+    if (strip) {
+        // one rank's strip of a large batch: its logits were kept by pass 1, its gradient rows are 16-row blocks of one launch --
+        // no B x B matrix of s dZ in HBM, no token-reduction contraction, no split reduction (139 -> ~100 us at B = 4096 / 512 rows)
+        static DeviceMax most;
+        const int lds = (int)B * 4;
+        if (raise_on_device(most, lds)) {
+            VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_strip_grad_kernel<ROWS_E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            raised_on_device(most, lds);
+        }
+        hipLaunchKernelGGL((nce_strip_grad_kernel<ROWS_E, 2>), dim3((unsigned)ceil_div(nrows, 16), 2, ROWS_E / 128), dim3(256), lds, s, w, (int)B,
+                           dx1, dx2, (int)row0, (int)nrows, grad_scale);
+        VIPANT_LAUNCH_CHECK();
+        return VIPANT_OK;
+    }
     // The token-reduction contraction wants its A operand 16-byte aligned, i.e. a strip starting on a multiple of 8 columns: a
     // rank's strip that does not (the reference's shipped default is 432 clips over 4 GPUs = 108 per rank) is widened to the left
     // by up to 7 columns, contracted into a scratch matrix, and its own rows copied out.

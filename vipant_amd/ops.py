@@ -587,6 +587,7 @@ class BackboneFn(torch.autograd.Function):
         st = _stream()
         saved: List[torch.Tensor] = []
         wts: List[Tuple[torch.Tensor, ...]] = []
+        kept_q: List = []           # per full block: (bytes, block scales) of ln_2's output (e4m3 towers with recompute_mlp)
         x = x.contiguous()
 
         def new(cols, dtype=BF16):
@@ -711,19 +712,26 @@ class BackboneFn(torch.autograd.Function):
                 gemm_nt(g, wpr_b, y2, bias=bpr, epi=EPI_BF16)
             else:
                 only_q = fp8 and not keep_mlp        # c_proj's operand is all that is wanted of g: neither g nor the codes are written
+                # `recompute_mlp` under e4m3: the LayerNorm output's e4m3 form is kept beside it (M D bytes + scales per block), so
+                # that the backward's c_fc launch needs no quantisation pass either
+                h2q = (torch.empty((M, D), dtype=torch.uint8, device=dev),
+                       torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)) if (fp8 and train and recompute_mlp) else None
                 call("vipant_ln_mlp_quickgelu_fwd_e4m3", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
                      wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
                      rstd2.data_ptr(), None if only_q else u.data_ptr(), None if only_q else g.data_ptr(), y2.data_ptr(), M, D,
-                     C.byref(fp8_plan(q_fc, q_pr, act, emit=emit)) if fp8 else None, sflags(x), st)
+                     C.byref(fp8_plan(q_fc, q_pr, h2q or act, emit=emit)) if fp8 else None, sflags(x), st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
                 saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2] + ([u, g] if keep_mlp else [])
+                if fp8 and recompute_mlp:
+                    kept_q.append(h2q)
             x, y_prev = x1, y2
         x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
+            ctx.kept_q = kept_q
             ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8, prune)
             ctx.rows = ridx
             ctx.last_ctx = ctx_alg
@@ -863,8 +871,11 @@ class BackboneFn(torch.autograd.Function):
                 continue
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
             if recompute_mlp:
-                call("vipant_mlp_quickgelu_recompute_e4m3", h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(), g.data_ptr(),
-                     M, D, C.byref(fp8_plan(wq4[2], None, act)) if fp8 else None, st)
+                h2q = ctx.kept_q[l] if fp8 else None
+                call("vipant_mlp_quickgelu_recompute_e4m3", None if fp8 else h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(),
+                     g.data_ptr(), M, D, C.byref(fp8_plan(wq4[2], None, h2q)) if fp8 else None, st)
+                if fp8:
+                    ctx.kept_q[l] = None
             else:
                 u, g = saved[ns * l + 11:ns * l + 13]
             # MLP half: c_proj^T + QuickGELU', c_fc^T, both weight gradients, ln_2 backward (+ residual gradient);
@@ -890,7 +901,7 @@ class BackboneFn(torch.autograd.Function):
             if ctx.grad_sync is not None:
                 ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
             lg = lg_below
-        ctx.wts = ctx.wqkv_b_last = None
+        ctx.wts = ctx.wqkv_b_last = ctx.kept_q = None
         need = ctx.needs_input_grad
         patch = ctx.patch_node                      # kept: a second backward over a retained graph hands over again
         if dx is None and need[0]:
@@ -1050,7 +1061,9 @@ class InfoNCEFn(torch.autograd.Function):
         dev = x1.device
         need = ctx.needs_input_grad
         want = need[0] or need[1] or need[2]
-        ws = scratch("infonce", query("vipant_infonce_workspace_bytes", B, E), dev)
+        # (gradients for a strip of a large batch -- one rank of an N-GPU step -- need a third of the workspace: no B x B matrices)
+        ws = scratch("infonce", query("vipant_infonce_strip_workspace_bytes", B, E, int(nrows)) if want
+                     else query("vipant_infonce_workspace_bytes", B, E), dev)
         loss = torch.empty((1,), dtype=F32, device=dev)
         d1 = torch.empty((nrows, E), dtype=F32, device=dev) if want else None
         d2 = torch.empty((nrows, E), dtype=F32, device=dev) if want else None
