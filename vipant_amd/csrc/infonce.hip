@@ -124,6 +124,24 @@ __global__ __launch_bounds__(256) void nce_prep_kernel(const float* __restrict__
     }
 }
 
+// bf16(x)^T for both operands in one launch (strip path, B % 32 == 0): 64 x 64 tiles through LDS, coalesced both ways
+__global__ __launch_bounds__(256) void nce_transpose_kernel(const float* __restrict__ x1, const float* __restrict__ x2, NceWs w, int B, int E) {
+    __shared__ bf16_t tile[64][66];
+    const float* src = blockIdx.z == 0 ? x1 : x2;
+    bf16_t* dst = blockIdx.z == 0 ? w.x1t : w.x2t;
+    const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = tr + r, gc = tc + tx;
+        tile[r][tx] = (gr < B && gc < E) ? (bf16_t)src[(int64_t)gr * E + gc] : (bf16_t)0.0f;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int gc = tc + c, gr = tr + tx;
+        if (gc < E && gr < w.Bp32) dst[(int64_t)gc * w.Bp32 + gr] = tile[tx][c];
+    }
+}
+
 template <int PASS>
 __global__ __launch_bounds__(512, 2) void nce_tile_kernel(NceWs w, int B, int K, int row0, int nrows, float gscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -577,52 +595,86 @@ __global__ __launch_bounds__(256) void nce_rows_grad_kernel(NceWs w, int B, floa
 // The gradient kernel of the strip path: nce_rows_grad_kernel's product for the rows [row0, row0 + nrows) of a LARGE batch -- the
 // strip's fp32-grade logits come from pass 1 (zrow / zcol), the log-sum-exp vectors from the merge kernel, so that nothing B x B is
 // stored and no split reduction follows: dx1[m] = sum_n s dZ[m, n] x2[n] (side 0, keys n) and dx2[m] = sum_n s dZ[n, m] x1[n] (side 1).
-template <int E, int CPW>
-__global__ __launch_bounds__(256) void nce_strip_grad_kernel(NceWs w, int B, float* __restrict__ dx1, float* __restrict__ dx2, int row0,
-                                                             int nrows, float gscale) {
-    extern __shared__ float lse_o[];            // log-sum-exp of the OTHER side, per key: B floats
+// A workgroup owns 16 rows x 128 columns; with thousands of keys the loop over them is a chain of memory round trips, so the four
+// waves split the KEYS (each forms s dZ of its quarter once, for all 128 columns) and add their partial tiles through LDS.
+// RT 16-row tiles per workgroup, NW waves splitting the keys.  Measured at B = 4096 / 512 rows: RT = 1, NW = 4: 44 us (the whole call 137-142);
+// NW = 8: the same (137-146); RT = 2 (half the re-reads of the transposed operand, half the workgroups): 66 us (160-165) -- the launch is
+// bound by round trips in flight on 256 CUs, not by bytes.  The call as a whole equals the tile path (139-144 us) in time: what both
+// spend is pass 1 over all 4096^2 logits (59 us, which the LOSS needs on every rank) plus four small launches; the strip path's gain
+// is the workspace (55 instead of 181 MB) and that no B x B matrix is written.
+template <int E, int RT, int NW>
+__global__ __launch_bounds__(NW * 64) void nce_strip_grad_kernel(NceWs w, int B, float* __restrict__ dx1, float* __restrict__ dx2, int row0,
+                                                                 int nrows, float gscale) {
+    extern __shared__ float lds_f[];            // [B] log-sum-exp of the OTHER side per key | [NW waves][RT][8 tiles][64 lanes] f32x4 partials
+    float* lse_o = lds_f;
+    f32x4* part = (f32x4*)(lds_f + ((B + 3) & ~3));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-    const int blk = blockIdx.x, side = blockIdx.y, col0 = blockIdx.z * (64 * CPW) + 16 * CPW * wave;
+    const int blk = blockIdx.x, side = blockIdx.y, col0 = blockIdx.z * 128;
     float* dx = side == 0 ? dx1 : dx2;
     if (dx == nullptr) return;
     const float* lo = side == 0 ? w.clse : w.rlse;
     const float* lq_all = side == 0 ? w.rlse : w.clse;
-    for (int n = threadIdx.x; n < B; n += 256) lse_o[n] = lo[n];
+    for (int n = threadIdx.x; n < B; n += NW * 64) lse_o[n] = lo[n];
     __syncthreads();
-    const int ml = 16 * blk + r;                 // row inside the strip
-    const int m = row0 + ml;
-    const bool live = ml < nrows;
-    const float lq = lq_all[live ? m : row0];
     const float s = w.scal[0], kf = gscale / (float)B * s;
-    const float* zrow = (side == 0 ? w.zrow : w.zcol) + (int64_t)(live ? ml : 0) * w.Bp128 + 8 * g;
-    const bf16_t* xt = (side == 0 ? w.x2t : w.x1t) + (int64_t)(col0 + r) * w.Bp32 + 8 * g;       // rows = this wave's columns
-    f32x4 acc[CPW];
+    int ml[RT], m[RT];
+    bool live[RT];
+    float lq[RT];
+    const float* zrow[RT];
 #pragma unroll
-    for (int ct = 0; ct < CPW; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nsteps = w.Bp32 / 32;
-#pragma unroll 4
-    for (int ks = 0; ks < nsteps; ++ks) {
-        const int k0 = 32 * ks;
-        bf16x8 xf[CPW];
-#pragma unroll
-        for (int ct = 0; ct < CPW; ++ct) xf[ct] = *(const bf16x8*)(xt + (int64_t)16 * ct * w.Bp32 + k0);
-        const f32x4 z0 = *(const f32x4*)(zrow + k0), z1 = *(const f32x4*)(zrow + k0 + 4);
-        bf16x8 bd;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int n = k0 + 8 * g + e;
-            const float z = e < 4 ? z0[e] : z1[e - 4];
-            float d = 0.f;
-            if (live && n < B) d = (__expf(z - lq) + __expf(z - lse_o[n]) - (m == n ? 2.f : 0.f)) * kf;
-            bd[e] = (bf16_t)d;
-        }
-#pragma unroll
-        for (int ct = 0; ct < CPW; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ct], bd, acc[ct], 0, 0, 0);
+    for (int t = 0; t < RT; ++t) {
+        ml[t] = 16 * (RT * blk + t) + r;              // row inside the strip
+        m[t] = row0 + ml[t];
+        live[t] = ml[t] < nrows;
+        lq[t] = lq_all[live[t] ? m[t] : row0];
+        zrow[t] = (side == 0 ? w.zrow : w.zcol) + (int64_t)(live[t] ? ml[t] : 0) * w.Bp128 + 8 * g;
     }
-    if (live) {
-        float* orow = dx + (int64_t)ml * E + col0 + 4 * g;
+    const bf16_t* xt = (side == 0 ? w.x2t : w.x1t) + (int64_t)(col0 + r) * w.Bp32 + 8 * g;       // rows = columns col0 + 16 ct + r
+    f32x4 acc[RT][8];
 #pragma unroll
-        for (int ct = 0; ct < CPW; ++ct) *(f32x4*)(orow + 16 * ct) = acc[ct];
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = w.Bp32 / 32;
+    const int per = (nsteps + NW - 1) / NW, ks0 = wave * per, ks1 = ks0 + per < nsteps ? ks0 + per : nsteps;
+#pragma unroll 2
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int k0 = 32 * ks;
+        bf16x8 xf[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) xf[ct] = *(const bf16x8*)(xt + (int64_t)16 * ct * w.Bp32 + k0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const f32x4 z0 = *(const f32x4*)(zrow[t] + k0), z1 = *(const f32x4*)(zrow[t] + k0 + 4);
+            bf16x8 bd;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int n = k0 + 8 * g + e;
+                const float z = e < 4 ? z0[e] : z1[e - 4];
+                float d = 0.f;
+                if (live[t] && n < B) d = (__expf(z - lq[t]) + __expf(z - lse_o[n]) - (m[t] == n ? 2.f : 0.f)) * kf;
+                bd[e] = (bf16_t)d;
+            }
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ct], bd, acc[t][ct], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) part[((wave * RT + t) * 8 + ct) * 64 + lane] = acc[t][ct];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if (!live[t]) continue;         // a wave adds the NW partials of its column tiles in a fixed order
+#pragma unroll
+        for (int u = 0; u < 8 / NW; ++u) {
+            const int ct = (8 / NW) * wave + u;
+            f32x4 v = part[((0 * RT + t) * 8 + ct) * 64 + lane];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v += part[((q * RT + t) * 8 + ct) * 64 + lane];
+            *(f32x4*)(dx + (int64_t)ml[t] * E + col0 + 16 * ct + 4 * g) = v;
+        }
     }
 }
 
@@ -665,8 +717,13 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     const char* rows_env = getenv("VIPANT_NCE_ROWS");
     const bool rows_path = B <= ROWS_MAX_B && E == ROWS_E && !(rows_env && rows_env[0] == '0');
     hipLaunchKernelGGL(nce_prep_kernel, dim3((unsigned)(pb > 2048 ? 2048 : pb)), dim3(256), 0, s, x1, x2, logit_scale,
-                       scale_max, w, (int)B, (int)E, (rows_path || strip) ? 1 : 0);
+                       scale_max, w, (int)B, (int)E, rows_path ? 1 : 0);
     VIPANT_LAUNCH_CHECK();
+    if (strip) {     // thousands of clips: the transposed bf16 copies through a tiled transpose (coalesced both ways)
+        hipLaunchKernelGGL(nce_transpose_kernel, dim3((unsigned)ceil_div(E, 64), (unsigned)ceil_div(w.Bp32, 64), 2), dim3(256), 0, s, x1, x2, w,
+                           (int)B, (int)E);
+        VIPANT_LAUNCH_CHECK();
+    }
     if (rows_path) {
         // few clips (the step's own batch on one GPU): 256 x 256 tiles would leave this on 4-16 CUs for three dependent
         // launches of 40-50 us each; row blocks of 16 against key chunks of 128 fill the chip and need no B x B operand in HBM
@@ -691,13 +748,14 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
         // one rank's strip of a large batch: its logits were kept by pass 1, its gradient rows are 16-row blocks of one launch --
         // no B x B matrix of s dZ in HBM, no token-reduction contraction, no split reduction (139 -> ~100 us at B = 4096 / 512 rows)
         static DeviceMax most;
-        const int lds = (int)B * 4;
+        constexpr int RT = 1, NW = 8;
+        const int lds = (int)((B + 3) / 4 * 4) * 4 + NW * RT * 8 * 64 * 16;
         if (raise_on_device(most, lds)) {
-            VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_strip_grad_kernel<ROWS_E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)nce_strip_grad_kernel<ROWS_E, RT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             raised_on_device(most, lds);
         }
-        hipLaunchKernelGGL((nce_strip_grad_kernel<ROWS_E, 2>), dim3((unsigned)ceil_div(nrows, 16), 2, ROWS_E / 128), dim3(256), lds, s, w, (int)B,
-                           dx1, dx2, (int)row0, (int)nrows, grad_scale);
+        hipLaunchKernelGGL((nce_strip_grad_kernel<ROWS_E, RT, NW>), dim3((unsigned)ceil_div(nrows, 16 * RT), 2, ROWS_E / 128), dim3(NW * 64), lds,
+                           s, w, (int)B, dx1, dx2, (int)row0, (int)nrows, grad_scale);
         VIPANT_LAUNCH_CHECK();
         return VIPANT_OK;
     }
