@@ -192,10 +192,12 @@ def test_image_head_golden(M, golden):
     assert rel_err(feat, g["feat"]) < 2e-2, rel_err(feat, g["feat"])
 
 
-# |loss - reference| budgets, about 2x the values observed on MI355X (profiles/r2_parity_observed.md); the north-star budget
-# of 1e-3 is for the loss kernel's own boundary (tests/test_kernels_gpu.py::test_infonce_golden, observed < 5e-5 x loss)
-E2E_LOSS_BUDGET = {"L2": 4e-3, "L12": 1e-3, "T1000": 3.5e-3,       # observed 2.1e-3 (b=8), 2.4e-4 (b=32), 1.7e-3 (b=4)
-                   "cfg2": 1e-3}      # the benchmarked shape at b = 64: the north-star budget itself
+# |loss - reference| budgets, about 2x the values observed on MI355X in round 5 (profiles/r5_parity_observed.jsonl; fp32 / fp16 stream):
+# L2 (b = 8, two blocks) 2.6e-3 / 3.3e-3; L12 (b = 32) 3.5e-4 / 4.7e-4; T1000 (b = 4) 1.3e-3 / 1.3e-3; cfg2 (the benchmarked shape, b = 64)
+# 3.9e-4 / 2.4e-4 against the north-star budget of 1e-3 itself.  History of cfg2: round 3 4.1e-4 / 4.9e-4, round 4 4.5e-4 / 6.0e-4 (the
+# folded last block rounded qk / contexts to bf16 per (item, head)), round 5 3.9e-4 / 2.4e-4 (those tensors travel as bf16 pairs).  The
+# loss kernel's own boundary: tests/test_kernels_gpu.py::test_infonce_golden, observed < 5e-5 x loss.
+E2E_LOSS_BUDGET = {"L2": 6e-3, "L12": 1e-3, "T1000": 3e-3, "cfg2": 1e-3}
 
 
 @pytest.mark.parametrize("stream", ["fp32", "fp16"])
@@ -442,7 +444,9 @@ def test_last_block_on_readout_rows_matches_full_block(M, kind, layers):
         assert err[name][0] < 2e-2 and err[name][0] < 1.5 * err["full"][0] + 2e-3, (name, err)
         assert err[name][1] < (8e-3 if kind == "text2" else 4e-3), (name, err)
         assert err[name][2] < 3e-2 and err[name][2] < 1.5 * err["full"][2] + 2e-3, (name, err)
-        # against the full block: two bf16 realisations of the same function (observed: profiles/r4_parity_observed.jsonl)
+        # against the full block: two bf16 realisations of the same function (observed: profiles/r5_parity_observed.jsonl: at these batch
+        # sizes -- 2 to 6 clips -- the FULL block's own loss error against the oracle is 0.4e-3 ... 5.2e-3, so its distance to any other
+        # realisation cannot be smaller; the folded form with bf16 pairs sits at 0.6e-3 ... 3.7e-3 from the oracle)
         assert rel_err(f1, f0) < 8e-3 and abs(l1 - l0) < (8e-3 if kind == "text2" else 4e-3), (name, rel_err(f1, f0), l0, l1)
         # (two clips: the 2 x 2 logits at scale 1 / 0.07 turn the features' rounding into the largest gradient differences seen here)
         for k in g0:
@@ -487,10 +491,12 @@ def test_end_to_end_golden_e4m3(M, golden, tag, L, b, T, Fq, rows):
     assert cls < E4M3_BUDGET[tag]["grad"] and fcb < E4M3_BUDGET[tag]["grad"], (cls, fcb)
 
 
-# about 2x the errors observed on MI355X (gpurun_out/parity_observed.jsonl, e2e_*_e4m3): loss 4.8e-3 / 1.05e-2, largest feature
-# component 8.9e-2 / 1.0e-1 (cosine >= 0.9955), gradient norms within 1.9 % / 4.1 %, rel-L2 of the two deepest gradients 0.16 / 0.18
-E4M3_BUDGET = {"L12": {"loss": 1e-2, "feat": 2e-1, "gnorm": 5e-2, "grad": 3.5e-1},
-               "cfg2": {"loss": 2e-2, "feat": 2e-1, "gnorm": 1e-1, "grad": 3.5e-1}}
+# about 2x the errors observed on MI355X (profiles/r5_parity_observed.jsonl, e2e_*_e4m3; rows / full last block).  Round 5: activations in
+# the MX block format (one scale per 32 elements instead of per row): loss 2.7e-3 / 2.1e-3 (L12), 2.9e-3 / 4.9e-3 (cfg2) -- round 4, row
+# scales: 6.6e-3 / 4.8e-3 and 5.0e-3 / 1.05e-2; largest feature component 8.3e-2 / 7.4e-2 (cosine >= 0.9955), gradient norms within
+# 3 % / 4 %, rel-L2 of the two deepest gradients 0.16 / 0.19
+E4M3_BUDGET = {"L12": {"loss": 6e-3, "feat": 2e-1, "gnorm": 6e-2, "grad": 3.5e-1},
+               "cfg2": {"loss": 1e-2, "feat": 2e-1, "gnorm": 1e-1, "grad": 3.5e-1}}
 
 
 def test_trainer_step_matches_oracle_lars():
@@ -772,11 +778,11 @@ def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
             else:
                 worst_norm = max(worst_norm, abs(dn / ref - 1))
     observe(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
-    # b = 8, two blocks: the bf16 towers' loss error at this batch size.  Observed on MI355X (profiles/r4_parity_observed.jsonl), worst
-    # of four steps: VA 1.7e-3 ... 3.0e-3 over the four (stream, last-block) corners, AT 2.7e-3 (fp32 stream, full block), 3.5e-3 / 3.6e-3
-    # (one of the two round-3 defaults on), 4.05e-3 (both): each default adds ~0.5-0.9e-3 at this size, neither owns the change.  The
-    # budget is 2x the largest observed value.
-    assert worst_loss < 8e-3, worst_loss
+    # b = 8, two blocks: the bf16 towers' loss error at this batch size.  Observed on MI355X in round 5 (profiles/r5_parity_observed.jsonl),
+    # worst of four steps over the (stream, last-block) corners: VA 1.6e-3 ... 3.2e-3, AT 1.6e-3 (fp32, rows), 2.2e-3 (fp32, full block),
+    # 2.5e-3 / 2.6e-3 (fp16 stream); round 4 had 4.05e-3 with both defaults on (bf16 qk / contexts in the folded last block).  One budget
+    # for every corner again: 5e-3, the value the (fp32, full block) corner always had.
+    assert worst_loss < 5e-3, worst_loss
     assert worst_norm < 6e-2, worst_norm                  # update norms: LARS trust ratio x gradient norm, bf16 gradient noise
     for k, p in named:
         if f"final_{k}" in g.files:
