@@ -4,7 +4,7 @@
 #   tests      the whole GPU suite
 #   bench      default bench.py line (20 steps) -> <tag>_bench.json
 #   shadow     tools/comm_shadow.py -> <tag>_comm_shadow.json
-#   prof       rocprofv3 kernel trace of 10 serial steps + per-shape table -> <tag>_kernel_stats_serial.csv, <tag>_kernel_shapes_serial.txt
+#   prof       rocprofv3 kernel trace of 13 serial steps (2 warm-up + 8 timed + the 3 of bench.py's serial post-pass) + per-shape table -> <tag>_kernel_stats_serial.csv, <tag>_kernel_shapes_serial.txt
 #   pmc        HBM traffic of the dominant kernels (separate --pmc passes) -> <tag>_pmc_traffic.json
 set -u
 batch=${1:-tests}; tag=${2:-r5}
@@ -16,10 +16,10 @@ case "$batch" in
   bench)  timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 3000 gpurun_out/${tag}_bench.json ;;
   shadow) timeout 1500 python tools/comm_shadow.py --out gpurun_out/${tag}_comm_shadow.json 2>&1 | tail -60 ;;
   prof)
-    rm -rf /tmp/prof && VIPANT_TOWER_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- \
+    rm -rf /tmp/prof && VIPANT_TOWER_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- \
         python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-full-last-block-check > gpurun_out/${tag}_bench_prof.json 2> gpurun_out/${tag}_prof.err
     f=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); cp "$f" gpurun_out/${tag}_kernel_stats_serial.csv
-    python tools/kstats_shapes.py /tmp/prof 10 > gpurun_out/${tag}_kernel_shapes_serial.txt
+    python tools/kstats_shapes.py /tmp/prof 13 > gpurun_out/${tag}_kernel_shapes_serial.txt
     head -40 gpurun_out/${tag}_kernel_shapes_serial.txt ;;
   pmc)
     rm -rf /tmp/pmc_f /tmp/pmc_w
