@@ -42,7 +42,9 @@ __device__ __forceinline__ void quant_row_mx(f32x4 (&o)[NV], uint8_t* __restrict
     }
 }
 
-template <int NV, typename XI, typename XO>  // D = NV * 256; XI / XO: the stream's element type on the way in / out
+// Q8: the e4m3 form of the output is written too.  A compile-time variant: the quantiser's registers in the plain kernel cost two waves
+// per SIMD of occupancy (72 -> 85 VGPRs at D = 768) and 25 us of a 180-us launch that lives on memory latency (round 5).
+template <int NV, typename XI, typename XO, bool Q8 = false>  // D = NV * 256; XI / XO: the stream's element type on the way in / out
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
             if (y32 != nullptr) *(f32x4*)(y32 + off) = o;
             v[t] = o;
         }
-        if (q8 != nullptr) quant_row_mx<NV>(v, q8 + row * D, q8s, row, lane);
+        if (Q8) quant_row_mx<NV>(v, q8 + row * D, q8s, row, lane);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
 // Per-block partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to `partial` [grid, 2, D].
 // DRES_BF16: the residual-stream gradient is a bf16 [M, D] tensor (read here, may be the same buffer as dxb: a lane reads its
 // elements of a row before it writes them) instead of an fp32 one.
-template <int NV, bool DY_F32, bool DRES_BF16, typename XT, int NWV>
+template <int NV, bool DY_F32, bool DRES_BF16, typename XT, int NWV, bool Q8 = false>
 __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const void* __restrict__ dy_, const XT* __restrict__ x,
                                                      int64_t ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const void* __restrict
             if (dxb != nullptr) *(bf16x4*)(dxb + row * D + col) = f32x4_to_bf16x4(o);
             g[t] = o;
         }
-        if (q8 != nullptr) quant_row_mx<NV>(g, q8 + row * D, q8s, row, lane);
+        if (Q8) quant_row_mx<NV>(g, q8 + row * D, q8s, row, lane);
     };
     // a ring of RING rows per wave: row r + (RING - 1) nwaves is requested before row r is reduced (static indices: the loop
     // body is written out RING times)
@@ -248,9 +250,14 @@ extern "C" int32_t vipant_layernorm_fwd_e4m3(const void* x, int64_t ldx, const f
     hipStream_t s = (hipStream_t)stream;
     // one row per wave, no grid-stride loop: 254 us against 286 us with 2048 persistent workgroups at M = 161 792 (1.49 GB)
     const int blocks = (int)(ceil_div(M, 4) > (1 << 20) ? (1 << 20) : ceil_div(M, 4));
-#define LN_FWD_T(NV, XI, XO)                                                                                              \
-    hipLaunchKernelGGL((ln_fwd_kernel<NV, XI, XO>), dim3(blocks), dim3(256), 0, s, (const XI*)x, ldx, gamma, beta, (bf16_t*)y, \
+#define LN_FWD_Q(NV, XI, XO, Q)                                                                                                 \
+    hipLaunchKernelGGL((ln_fwd_kernel<NV, XI, XO, Q>), dim3(blocks), dim3(256), 0, s, (const XI*)x, ldx, gamma, beta, (bf16_t*)y, \
                        y_f32, mean, rstd, M, (const bf16_t*)add, (XO*)sum_out, q, qscale)
+    // (the quantising variants exist for the fp16 stream inside the stacks, which is where e4m3 towers run them)
+#define LN_FWD_T(NV, XI, XO)                                                      \
+    do {                                                                          \
+        if (q != nullptr) LN_FWD_Q(NV, XI, XO, true); else LN_FWD_Q(NV, XI, XO, false); \
+    } while (0)
 #define LN_FWD(NV)                                                              \
     do {                                                                        \
         if (in16 && out16) LN_FWD_T(NV, f16_t, f16_t);                          \
@@ -266,6 +273,7 @@ extern "C" int32_t vipant_layernorm_fwd_e4m3(const void* x, int64_t ldx, const f
     }
 #undef LN_FWD
 #undef LN_FWD_T
+#undef LN_FWD_Q
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -298,9 +306,13 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
     VIPANT_REQUIRE(!(dres_bf16 && (dres == nullptr || dy_is_f32)), VIPANT_EBADSHAPE,
                    "layernorm_bwd: a bf16 residual gradient needs dres and a bf16 dy");
     const bool x16 = (flags & VIPANT_LN_X_F16) != 0;
-#define LN_BWD_T(NV, A, B, XT)                                                                                                 \
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, A, B, XT, 4>), dim3(blocks), dim3(256), 0, s, dy, (const XT*)x, ldx, mean, rstd, gamma, \
+#define LN_BWD_Q(NV, A, B, XT, Q)                                                                                                 \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, A, B, XT, 4, Q>), dim3(blocks), dim3(256), 0, s, dy, (const XT*)x, ldx, mean, rstd, gamma, \
                        dres, dx_f32, lddx, (bf16_t*)dx_bf16, partial, M, q, qscale)
+#define LN_BWD_T(NV, A, B, XT)                                                            \
+    do {                                                                                  \
+        if (q != nullptr) LN_BWD_Q(NV, A, B, XT, true); else LN_BWD_Q(NV, A, B, XT, false); \
+    } while (0)
 #define LN_BWD(NV)                                                                                                   \
     do {                                                                                                             \
         if (dy_is_f32) { if (x16) LN_BWD_T(NV, true, false, f16_t); else LN_BWD_T(NV, true, false, float); }         \
@@ -315,6 +327,7 @@ extern "C" int32_t vipant_layernorm_bwd_e4m3(const void* dy, int32_t flags, cons
     }
 #undef LN_BWD
 #undef LN_BWD_T
+#undef LN_BWD_Q
     VIPANT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((unsigned)ceil_div(3 * D, 64)), dim3(1024), 0, s,
                        (const float*)partial, blocks, (int)D, dgamma, dbeta, dx_colsum, accumulate);
