@@ -581,7 +581,8 @@ template <int V> struct Int { static constexpr int value = V; };
 // ES = bytes per operand element: 2 = bf16 (K-tile of 64), 1 = e4m3 with per-row power-of-two scales (K-tile of 128: the same
 // 128-byte rows, the same LDS images, DMA stream and barrier schedule; half the MFMA instructions, each twice as long, for
 // twice the K -- twice the FLOP per byte moved and per cycle).
-template <int EPI, int VAR, int ES = 2, int EMIT = 0>
+// DYN: the ticket walk (compile-time: the static walk's kernels are byte for byte what they were before it existed).
+template <int EPI, int VAR, int ES = 2, int EMIT = 0, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -610,33 +611,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // mailbox (two words, alternating), and every wave reads that word in the bias round trip of the tile after that.  A workgroup
     // therefore holds claims on three tiles beyond the one it computes.  (gemm_nt.hip is compiled with the atomic optimizer off:
     // it turns a uniform atomic into "first lane adds, wait, broadcast" -- a full wait where the draw is issued.)
-    // (the e4m3 QuickGELU kernel keeps the static walk: it sits at the 256-register limit, and the ticket state is what spills)
-    const bool dyn = (ES != 1 || EPI != VIPANT_EPI_QUICKGELU_D8) && p.tk != nullptr;
+    // All of the walk's state lives in VECTOR registers on purpose (the `"+v"` launderings below): the K-loop keeps ~100 scalars busy
+    // with buffer descriptors and offsets, and a dozen more made hipcc spill 27 of them into VGPR lanes -- 70 v_readlane / v_writelane
+    // and 290 hazard s_nops in the loop: +5 % on the c_fc launch, whichever walk ran (round 5, same-box A/B against the round-4 tree).
+    constexpr bool dyn = DYN;
     constexpr int NO_TILE = 0x3FFFFFFF;
-    const int xq = blockIdx.x & 7;
-    int qlen_own;
-    if (GROUPED) {
-        int rows = ntm - (xq & 3) * ppx;
-        rows = rows < 0 ? 0 : (rows > ppx ? ppx : rows);
-        qlen_own = rows * cg;
-    } else {
-        int rem = (ntiles & 255) - xq * 32;
-        rem = rem < 0 ? 0 : (rem > 32 ? 32 : rem);
-        qlen_own = (ntiles >> 8) * 32 + rem;
+    int xq = blockIdx.x & 7;
+    int qlen_own = 0;
+    uint32_t* mbox = nullptr;                   // this workgroup's two mailbox words
+    uint32_t* tkq = nullptr;                    // its queue's counter
+    if (DYN) {
+        if (GROUPED) {
+            int rows = ntm - (xq & 3) * ppx;
+            rows = rows < 0 ? 0 : (rows > ppx ? ppx : rows);
+            qlen_own = rows * cg;
+        } else {
+            int rem = (ntiles & 255) - xq * 32;
+            rem = rem < 0 ? 0 : (rem > 32 ? 32 : rem);
+            qlen_own = (ntiles >> 8) * 32 + rem;
+        }
+        mbox = p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x;
+        tkq = p.tk + xq;
+        asm volatile("" : "+v"(xq), "+v"(qlen_own), "+v"(mbox), "+v"(tkq));
     }
-    uint32_t* const mbox = dyn ? p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x : nullptr;
     uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 96 + value)
-    bool tk_dry = false;                        // thread 0: the queue is empty, stop drawing
+    int tk_dry = 0;                             // thread 0: the queue is empty, stop drawing
     int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
-    bool tk_first = true;                       // the first tile's round trip has nothing to read: its "ticket" is the third static tile
+    int tk_first = 1;                           // the first tile's round trip has nothing to read: its "ticket" is the third static tile
+    if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first));
     auto tk_tile = [&](uint32_t drawn) {
         const int pos = 96 + (int)drawn;
         if (pos < qlen_own) return tickets::tile_of(xq, pos);
-        tk_dry = true;
+        tk_dry = 1;
         return NO_TILE;
     };
     if (dyn && tid == 0) {
-        tk_pend = tickets::take(p.tk + xq);     // this workgroup's fourth tile; not awaited before the first tile's bias round trip
+        tk_pend = tickets::take(tkq);           // this workgroup's fourth tile; not awaited before the first tile's bias round trip
         // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
         // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
         if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
@@ -875,6 +885,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
                     if (tid == 0) tickets::post(mbox + (tk_par ^ 1), tk_post);
                     tk_par ^= 1;
+                    asm volatile("" : "+v"(tk_par));
                 }
                 // (issued behind the waits above -- the code bytes come from HBM -- and not awaited here)
                 if (PRE_CODES) load_codes(p, cur.m0, cur.n0, grp, tid & 255, 0, cn_pre);
@@ -947,11 +958,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
-        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(p.tk + xq);        // not awaited here
+        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(tkq);        // not awaited here
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile = tile_nxt;
-        tile_nxt = (dyn && !tk_first) ? tk_next_s : tile_nxt + G;
-        tk_first = false;
+        tile_nxt = (dyn && !__builtin_amdgcn_readfirstlane(tk_first)) ? tk_next_s : tile_nxt + G;
+        if (DYN) { tk_first = 0; asm volatile("" : "+v"(tk_first)); }
         cur = nxt;
         nxt = describe(tile_nxt);
         if (ES == 1) sbv = sbv_n;
@@ -962,10 +973,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 
 template <int EPI, int VAR, int ES = 2, int EMIT = 0>
 int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
+    // the ticket walk exists for the bf16 kernels (the e4m3 ones sit at the 256-register limit: BASELINE configs[4] keeps the static walk)
+    constexpr bool CAN_DYN = ES == 2;
     static DeviceOnce once;
     if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES, EMIT>,
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES, EMIT, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        if (CAN_DYN)
+            VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, VAR, ES, EMIT, CAN_DYN>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
         done_on_device(once);
     }
     GemmNT p = p_in;
@@ -977,11 +993,14 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     const int64_t ppx = (ntm + 3) / 4;
     const int64_t shortest = VAR == 8 ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
                                       : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
-    if (grid == 256 && shortest > 96 && !(p.dbg & 4194304) && !(ES == 1 && EPI == VIPANT_EPI_QUICKGELU_D8)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
+    if (CAN_DYN && grid == 256 && shortest > 96 && !(p.dbg & 4194304)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
         p.tk = vipant_ticket_block(stream, &p.tk_other);
         if (p.tk == nullptr) return VIPANT_EHIP;
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES, EMIT, CAN_DYN>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
+        VIPANT_LAUNCH_CHECK();
+        return VIPANT_OK;
     }
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES, EMIT>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES, EMIT, false>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
