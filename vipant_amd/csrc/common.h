@@ -198,6 +198,14 @@ __device__ __forceinline__ void post(uint32_t* p, uint32_t v) { __hip_atomic_sto
 __device__ __forceinline__ uint32_t peek(const uint32_t* p) {
     return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
+// the same three on a GLOBAL address carried as an integer in vector registers (a pointer laundered through `asm("" : "+v")` loses its
+// address space: hipcc then emits flat accesses, which wait on vmcnt AND lgkmcnt and make it put vmcnt(0) in front of LDS reads)
+typedef __attribute__((address_space(1))) uint32_t gu32_t;
+__device__ __forceinline__ uint32_t take_g(uint64_t a) {
+    return __hip_atomic_fetch_add((gu32_t*)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void post_g(uint64_t a, uint32_t v) { __hip_atomic_store((gu32_t*)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ uint32_t peek_g(uint64_t a) { return __hip_atomic_load((gu32_t*)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 // position s of queue q -> the tile the static walk of a 256-workgroup grid gave workgroup q + 8 (s & 31) in its round s >> 5
 __device__ __forceinline__ int tile_of(int q, int s) { return (s >> 5) * 256 + q * 32 + (s & 31); }
 }  // namespace tickets

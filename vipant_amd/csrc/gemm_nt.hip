@@ -618,8 +618,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     constexpr int NO_TILE = 0x3FFFFFFF;
     int xq = blockIdx.x & 7;
     int qlen_own = 0;
-    uint32_t* mbox = nullptr;                   // this workgroup's two mailbox words
-    uint32_t* tkq = nullptr;                    // its queue's counter
+    uint64_t mbox = 0;                          // this workgroup's two mailbox words (global address)
+    uint64_t tkq = 0;                           // its queue's counter
     if (DYN) {
         if (GROUPED) {
             int rows = ntm - (xq & 3) * ppx;
@@ -630,8 +630,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             rem = rem < 0 ? 0 : (rem > 32 ? 32 : rem);
             qlen_own = (ntiles >> 8) * 32 + rem;
         }
-        mbox = p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x;
-        tkq = p.tk + xq;
+        mbox = (uint64_t)(p.tk + VIPANT_TICKET_MBOX + 2 * blockIdx.x);
+        tkq = (uint64_t)(p.tk + xq);
         asm volatile("" : "+v"(xq), "+v"(qlen_own), "+v"(mbox), "+v"(tkq));
     }
     uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 96 + value)
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         return NO_TILE;
     };
     if (dyn && tid == 0) {
-        tk_pend = tickets::take(tkq);           // this workgroup's fourth tile; not awaited before the first tile's bias round trip
+        tk_pend = tickets::take_g(tkq);         // this workgroup's fourth tile; not awaited before the first tile's bias round trip
         // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
         // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
         if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
@@ -854,8 +854,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // the kernel's last statement reads them.  hipcc protects a register that a load / store in flight still names with a vmcnt wait
     // in front of its next writer: a wait behind LDS-DMA pieces or code loads wherever the allocator happened to reuse it.)
     uint32_t tk_next = 0u, tk_post = 0u;
+    int tk_next_s = NO_TILE;
     while (tile < ntiles) {
-        int tk_next_s = NO_TILE;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -869,21 +869,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             // the ticket of the tile after the next: read one K-tile ahead of the bias round trip, which then finds it landed (a CU's
             // memory pipeline is in order: read IN that round trip, the load waits behind the DMA pieces in flight, +0.9 us per
             // tile on the launches without a bias)
-            if (dyn && k == nk - 2) tk_next = tickets::peek(mbox + tk_par);
+            if (dyn && k == nk - 2) tk_next = tickets::peek_g(mbox + 4 * tk_par);
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
                 if (ES == 1) load_b_scales(nxt, sbv_n);                       // the next tile's weight scales ride the same round trip
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
                 if (ES == 1) asm volatile("" : "+v"(sbv_n));
-                if (dyn) {      // older than the loads above: awaited with them, and kept as a scalar from here (a vector register that
-                    asm volatile("" : "+v"(tk_next));     // "may be pending" costs a vmcnt wait behind the epilogue's stores)
-                    tk_next_s = __builtin_amdgcn_readfirstlane((int)tk_next);
-                }
                 if (dyn) {
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
                     tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
-                    if (tid == 0) tickets::post(mbox + (tk_par ^ 1), tk_post);
+                    if (tid == 0) tickets::post_g(mbox + 4 * (tk_par ^ 1), tk_post);
                     tk_par ^= 1;
                     asm volatile("" : "+v"(tk_par));
                 }
@@ -954,11 +950,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             ++gk;
             slot = slot1;
             if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; }
+            // the ticket read at the top of this K-tile is older than the K-tile's eight pieces: the counted wait that ended it has
+            // retired it, and in straight-line code hipcc's own wait for it is that same vmcnt(8) -- not the vmcnt(0) it puts in
+            // front of a use one iteration later (which, on the launches without a bias, waited for every piece in flight: +58 us
+            // on the QuickGELU' launch).  From here the ticket is a scalar.
+            if (dyn && k == nk - 2) tk_next_s = __builtin_amdgcn_readfirstlane((int)tk_next);
         }
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
-        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take(tkq);        // not awaited here
+        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take_g(tkq);      // not awaited here
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile = tile_nxt;
         tile_nxt = (dyn && !__builtin_amdgcn_readfirstlane(tk_first)) ? tk_next_s : tile_nxt + G;
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         if (ES == 1) sbv = sbv_n;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
-    if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
+    if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post_g(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
 }
 
 template <int EPI, int VAR, int ES = 2, int EMIT = 0>
