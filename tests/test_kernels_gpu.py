@@ -395,12 +395,43 @@ def test_mha(ops, batch, S, H, causal):
     assert_close(dqkv, qr.grad, 2e-2, 2e-2 * scale, "mha bwd")
 
 
+@pytest.mark.parametrize("batch,H,S", [(60, 12, 316), (171, 3, 306), (43, 12, 300)])
+def test_mha_bwd_ticket_walk_equals_static_walk(ops, monkeypatch, batch, H, S):
+    """Round 5: the persistent attention backward (mha_bwd1s_kernel, one workgroup per CU) draws its third and later problems from the
+    stream's ticket counter when batch * heads > 2 x CUs (720, 513 and 516 problems here: long queues, a single drawn problem, four).
+    Which workgroup computes a problem must not matter: bit-identical to the static stride (VIPANT_GEMM_VARIANT bit 22), alone and with
+    CUs held by `vipant_comm_shadow` on a second stream, repeatedly (the counters must be back at zero for every launch, also when a
+    ticket-walk NT contraction runs in between on the same stream)."""
+    D = H * 64
+    qkv = rnd(batch * S, 3 * D, seed=11, dtype=torch.bfloat16, scale=1.5)
+    dout = rnd(batch * S, D, seed=12, dtype=torch.bfloat16)
+    out, lse = ops.mha_fwd(qkv, batch, S, H, False)
+    src = torch.empty(28 << 20, dtype=torch.uint8, device=DEV); dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    a = rnd(40448, 768, seed=13, dtype=torch.bfloat16); w = rnd(768, 768, seed=14, dtype=torch.bfloat16, scale=0.03)
+    c = torch.empty(40448, 768, dtype=torch.bfloat16, device=DEV)
+    monkeypatch.setenv("VIPANT_GEMM_VARIANT", "4194304")
+    ref = ops.mha_bwd(qkv, out, dout, lse, batch, S, H, False)
+    assert torch.isfinite(ref.float()).all()
+    monkeypatch.setenv("VIPANT_GEMM_VARIANT", "0")
+    for held, us in [(0, 0.0), (64, 300.0), (0, 0.0), (24, 2000.0), (0, 0.0)]:
+        if held:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.call("vipant_comm_shadow", src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
+        else:
+            ops.gemm_nt(a, w, c, epi=ops.EPI_BF16)
+        got = ops.mha_bwd(qkv, out, dout, lse, batch, S, H, False)
+        assert torch.equal(ref, got), (held, us)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("key,gain", [(7, 40), (200, 40), (200, 250), (7, 250), (315, 250), (170, 120)])
 def test_mha_spiky_scores(ops, key, gain):
-    """A dominant key per query (exact-softmax path must not lose it to rounding / masking).  The wide forward (csrc/attention_wide.hip)
-    takes a whole query block's keys in two halves and exponentiates the second half against the FIRST half's maximum unless that would
-    overflow: keys in either half, with a lead small enough for the common path (gain 40: 18 in the exponent) and large enough to
-    force the rescale branch (gain 250: > 64), on the whole blocks (query 100) and on the block two waves share (query 300)."""
+    """A dominant key per query (the softmax must not lose it to rounding / masking): keys in the first and the second half of a
+    query block's key range, with a lead of 18 in the exponent (gain 40) and of more than 64 (gain 250: a kernel that exponentiates
+    against a partial maximum -- the wide forward kept as text under tools/probes/ did -- has to rescale), on whole query blocks
+    (query 100) and on the block two waves share (query 300)."""
     batch, S, H = 1, 316, 1
     qkv = rnd(S, 192, seed=3, dtype=torch.bfloat16, scale=0.2)
     qkv[:, 64:128][key] = qkv[:, :64][100] * gain       # key aligned with query 100

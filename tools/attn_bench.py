@@ -28,6 +28,6 @@ def timeit(fn, n=5):
 out, lse = ops.mha_fwd(qkv, b, S, H, False)
 fl = 4.0 * b * H * S * S * 64
 t = timeit(lambda: ops.mha_fwd(qkv, b, S, H, False))
-print(f"waves={os.environ.get('VIPANT_ATTN_WAVES', '8')} fwd {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s")
+print(f"fwd {t * 1e3:8.1f} us  {fl / t / 1e9:7.1f} TFLOP/s")
 t = timeit(lambda: ops.mha_bwd(qkv, out, dout, lse, b, S, H, False))
-print(f"waves={os.environ.get('VIPANT_ATTN_WAVES', '8')} bwd {t * 1e3:8.1f} us  {2.5 * fl / t / 1e9:7.1f} TFLOP/s (5 products)")
+print(f"bwd {t * 1e3:8.1f} us  {2.5 * fl / t / 1e9:7.1f} TFLOP/s (5 products)")

@@ -1,4 +1,4 @@
-"""Static-stride vs ticket tile walk of the persistent NT kernels (VIPANT_GEMM_VARIANT bit 22), per launch shape of the VA step,
+"""Static-stride vs ticket walk of the persistent kernels (NT contractions, attention backward; VIPANT_GEMM_VARIANT bit 22), per launch shape of the VA step,
 alternating in one process: python tools/walk_ab.py [rounds]"""
 import os
 import sys
@@ -32,6 +32,11 @@ cases = [
     ("dh1    N=768  K=2304", lambda: ops.gemm_nt(x2304, w_q2, o768, epi=ops.EPI_BF16)),
     ("out    N=768  K=768 ", lambda: ops.gemm_nt(x768, w_o, o768, bias=b768, epi=ops.EPI_BF16)),
 ]
+# the persistent attention backward (6144 problems on 256 workgroups), same switch
+qkv = rb(M, 2304)
+att, lse = ops.mha_fwd(qkv, 512, 316, 12, False)
+datt = rb(M, 768)
+cases.append(("mha_bwd b=512 S=316 ", lambda: ops.mha_bwd(qkv, att, datt, lse, 512, 316, 12, False)))
 
 
 def one(fn):

@@ -505,7 +505,7 @@ __device__ unsigned long long g_attn_stamps[64];
 // of LDS (no global round trip, no 320-row pass up front).  The workgroup is persistent, the ring runs on across problems: a
 // problem's first steps, its K image, its statistics are all in place when the previous problem's dK / dV leave.
 // LDS: K images 2 x 40 KiB | X 2 x 20 KiB | ring 4 x (Q 4 KiB + dO 4 KiB) | delta 2 x 32 floats | O rows 4 x 1 KiB | lse 4 x 256 B
-// = 157.25 KiB.  NOTHING inside the loop is loaded into registers from global memory: every request is an LDS-DMA piece (inline
+// (+ 16 B: the ticket) = 157.27 KiB.  NOTHING inside the loop is loaded into registers from global memory: every request is an LDS-DMA piece (inline
 // asm, so that hipcc's wait insertion does not see it; explicit counted vmcnt waits).  An asm load into registers whose wait comes
 // a step later is not safe -- the register allocator may park the "loaded" value elsewhere before the data has arrived -- and a
 // compiler-visible load would be awaited together with every piece in flight.  The O rows and lse words a wave needs for its
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
     float* const sdel = (float*)(ring + 4 * STG);      // [2][32]
     char* const obuf = ring + 4 * STG + 256;           // [4 waves][8 rows x 128 B]: the O rows a wave's threads take delta from
     char* const lbuf = obuf + 4096;                    // [4 waves][64 floats]: lse of a step's queries (32 used), one copy per wave
+    LDS_AS uint32_t* const tkw = (LDS_AS uint32_t*)(lbuf + 1024);    // the ticket drawn during a problem, for every wave (see the walk below)
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int D = p.H * 64, ld = 3 * D;
@@ -596,8 +597,26 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
         if (c0 == 0) sdel[dbuf * 32 + row] = sacc;
     };
 
-    // ---- preamble: the first problem's K image, its first three stages, its V fragments, lse of step 0, O of steps 0 and 1
+    // ---- the walk over problems.  A problem needs its successor's index at its START (the successor's K image, first stages and
+    // V fragments are requested under this problem's arithmetic), so the draw runs one problem ahead of that: problems 0 and 1 of
+    // a workgroup are static (blockIdx.x, blockIdx.x + grid); during problem t thread 0 draws the index of problem t + 2 from the
+    // stream's counter (one agent-scope atomic, issued before the next problem's V loads and therefore covered by the same counted
+    // wait at the problem's end), puts it into LDS before the problem's last barrier, and every wave reads it from there.  A
+    // workgroup held up by a co-resident kernel simply draws fewer problems.  Results do not depend on who computes a problem.
+    // p.tk == NULL: the static stride.  The atomic is inline asm (result in an accumulation register, as the V loads: the compiler
+    // must not see a load it would wait for); all four waves issue it, with EXEC = lane 0 of wave 0 only and EXEC = 0 elsewhere.
+    const bool dyn = p.tk != nullptr;
+    if (dyn && blockIdx.x == 0 && threadIdx.x < 8) tickets::put(p.tk_other + threadIdx.x, 0u);
+    auto draw = [&]() {
+        uint32_t raw;
+        uint64_t keep;
+        const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane(dyn && wave == 0 ? 1 : 0);
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %3, %4, off sc0\n\ts_mov_b64 exec, %1"
+                     : "=&a"(raw), "=&s"(keep) : "s"(who), "v"((uint64_t)p.tk), "a"(1u) : "memory");
+        return raw;
+    };
     int prob = blockIdx.x;
+    int nxt = blockIdx.x + gridDim.x;
     int gs = 0;                                        // global step counter: ring slot = gs & 3, delta buffer = gs & 1
     int cur = 0;                                       // K image in use
     bf16x8 vf[KPW][2];
@@ -633,14 +652,14 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (in the steady state the last step of the previous problem waits for it)
     }
 
-  for (; prob < nprob; prob += gridDim.x, cur ^= 1) {
+  for (; prob < nprob; cur ^= 1) {
     // (the lane index is laundered per problem: per-lane addresses are recomputed here instead of being kept across the loop)
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int tid = wave * 64 + lane;
     const int kcol = lane & 15, g = lane >> 4;
     const LaneK lk = make_lanek(lane);
-    const Prob pn = make_prob(prob + gridDim.x);
+    const Prob pn = make_prob(nxt);
     char* const kimg = smem + cur * KIMG;
     char* const knext = smem + (cur ^ 1) * KIMG;
 
@@ -875,6 +894,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
     };
     a_stage(Int2<KPW - 1>{}, pf_c, dsf_c);
     // the V fragments' registers are free: request the next problem's (awaited at the end of this problem, behind the dK / dV stores)
+    const uint32_t tk_raw = draw();                    // (older than the V loads: the wait for those covers it)
     v_load(pn, lane);
     dq0 = f32x4{0.f, 0.f, 0.f, 0.f}; dq1 = f32x4{0.f, 0.f, 0.f, 0.f};
     p_stage(xbuf + ((NU - 1) & 1) * XB + xrd, 0, NU);
@@ -911,10 +931,13 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
     STAMP(14);
     // the next problem's V fragments (10 loads) went out before this problem's 2 + 20 stores
     asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    if (dyn && tid == 0) *tkw = 2u * gridDim.x + tk_raw;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // staging rows read: X may be written again; (the other K image is complete:
     STAMP(15);
     pc = pn;
+    prob = nxt;
+    nxt = dyn ? __builtin_amdgcn_readfirstlane((int)*tkw) : nxt + (int)gridDim.x;
   }                                                    // its last piece was awaited at the end of step 9)
 }
 
@@ -1255,14 +1278,21 @@ int32_t launch_bwd_nw(const MhaArgs& a, hipStream_t s) {
 
 template <int NT>
 int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024;
+    constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024 + 16;
     static DeviceOnce once;
     if (first_on_device(once)) {
         VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done_on_device(once);
     }
     const int nprob = a.batch * a.H, cus = device_cus();       // one persistent workgroup per CU
-    hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, a);
+    MhaArgs t = a;
+    // ticket walk when a workgroup has problems beyond its two static ones (bit 22 of VIPANT_GEMM_VARIANT: static, for A/B runs)
+    const char* var = getenv("VIPANT_GEMM_VARIANT");
+    if (nprob > 2 * cus && !(var && (atoi(var) & 4194304))) {
+        t.tk = vipant_ticket_block(s, &t.tk_other);
+        if (!t.tk) return VIPANT_EHIP;
+    }
+    hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, t);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }

@@ -16,6 +16,8 @@ struct MhaArgs {
     const bf16_t* dout; float* delta; bf16_t* dqkv;
     int batch, S, H;
     int stagger;
+    uint32_t* tk = nullptr;            // ticket counters of the stream (common.h) for the persistent backward; NULL = static walk
+    uint32_t* tk_other = nullptr;      // the stream's other counter set, zeroed by this launch
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
