@@ -1,4 +1,4 @@
-"""Cycle stamps of one wave of mha_bwd1_kernel (debug build with -DVIPANT_ATTN_STAMPS, loaded through VIPANT_HIP_LIB)."""
+"""Cycle stamps of one wave of the round-3 resident-image backward (tools/probes/mha_bwd1_resident.hip.txt; debug build with -DVIPANT_ATTN_STAMPS, loaded through VIPANT_HIP_LIB).  attn_stamps_s.py is the shipped streamed kernel's."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from vipant_amd import ops, _ffi

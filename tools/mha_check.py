@@ -1,4 +1,4 @@
-"""Attention kernels: accuracy against an fp64 reference and timing, for whatever VIPANT_ATTN_FWD / VIPANT_ATTN_BWD select.
+"""Attention kernels: accuracy against an fp64 reference and timing of the shipped kernels (the opt-in builds of rounds 3-4 live as text under tools/probes/).
 usage: python tools/mha_check.py [tag]"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
