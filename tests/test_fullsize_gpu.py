@@ -272,3 +272,45 @@ def test_vit_l_depth_sample_independence(ops):
             acc[k] += p.grad.double()
     for k in full:
         assert max_rel(full[k], acc[k]) < 1e-4, (k, max_rel(full[k], acc[k]))
+
+
+def test_cfg5_full_size_tower_step(ops):
+    """BASELINE.json configs[4]'s tower at FULL size in the driver's own test run ("nothing driver-run has
+    allocated that step"): audio ViT-L stack (24 blocks, width 1024, 16 heads), 1024 clips x 316 tokens = 323 584 token rows, e4m3
+    contractions with MX block scales, recomputed MLP activations (~150 GB; without recomputation the step fits too, 235 GB:
+    profiles/r5_cfg5_mx.md).  One forward + backward; the first and last four clips' outputs and input gradients equal, bit for bit,
+    those of 4-clip runs (samples are independent through the stack and the block quantiser works inside a token row, so the
+    1024-clip numerics are the ones tests/test_model_gpu.py pins to the reference at small batches)."""
+    import vipant_amd.module as Mod
+    if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    torch.cuda.empty_cache()
+    layers, width, b = 24, 1024, 1024
+    bb = Mod.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=width, ctx_len=None)
+    w = gen.det_weights("full/1024", gen.backbone_shapes(width, layers))
+    bb.load_state_dict({k[len("encoder."):]: v for k, v in w.items()}, strict=True)
+    bb = bb.to(DEV)
+    bb.fp8, bb.recompute_mlp = True, True
+    x = rnd(b, S, width, seed=31)
+    gy = rnd(b, S, width, seed=32)
+    torch.cuda.reset_peak_memory_stats()
+    xf = x.clone().requires_grad_()
+    yf = bb(xf)
+    yf.backward(gy)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    print(f"cfg5 tower step at 1024 clips: peak {peak:.1f} GB")
+    assert torch.isfinite(yf).all() and torch.isfinite(xf.grad).all()
+    for k, p in bb.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+    keep = [(c, yf[c:c + 4].clone(), xf.grad[c:c + 4].clone()) for c in (0, b - 4)]
+    del yf, xf
+    for p in bb.parameters():
+        p.grad = None
+    torch.cuda.empty_cache()
+    for c, y_ref, dx_ref in keep:
+        xs = x[c:c + 4].clone().requires_grad_()
+        ys = bb(xs)
+        ys.backward(gy[c:c + 4])
+        assert torch.equal(ys, y_ref), c
+        assert torch.equal(xs.grad, dx_ref), c

@@ -879,8 +879,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 if (dyn) {
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
                     tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
-                    if (tid == 0) tickets::post_g(mbox + 4 * (tk_par ^ 1), tk_post);
-                    tk_par ^= 1;
+                    tk_par ^= 1;                 // (the store itself goes out at the start of the epilogue, in front of the tile's own stores)
                     asm volatile("" : "+v"(tk_par));
                 }
                 // (issued behind the waits above -- the code bytes come from HBM -- and not awaited here)
@@ -959,7 +958,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
         if (DEEP) stg = smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT + grp * 16384;   // the last K-tile's B slot: read and done
-        if (dyn && tid == 0 && !tk_dry) tk_pend = tickets::take_g(tkq);      // not awaited here
+        // the mailbox store goes here and not next to the bias: there it was the first operation behind a full wait, and the next
+        // counted wait -- which lets the K-tile's eight pieces stay in flight -- had to see its acknowledgement first (+0.5 us per tile
+        // on the launches with a bias); here the tile's own stores queue up behind it and nobody waits for it in particular
+        if (dyn && tid == 0) {
+            tickets::post_g(mbox + 4 * tk_par, tk_post);
+            if (!tk_dry) tk_pend = tickets::take_g(tkq);      // not awaited here
+        }
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         tile = tile_nxt;
         tile_nxt = (dyn && !__builtin_amdgcn_readfirstlane(tk_first)) ? tk_next_s : tile_nxt + G;
