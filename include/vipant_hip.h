@@ -98,6 +98,7 @@ int32_t vipant_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, co
 #define VIPANT_STREAM_IN_F16 1
 #define VIPANT_STREAM_OUT_F16 2
 #define VIPANT_STREAM_FEW_ROWS 0x100 /* (vipant_ln_mlp_quickgelu_bwd_e4m3) its contractions are VIPANT_EPI_FEW_ROWS launches */
+#define VIPANT_STREAM_ACT_Q 0x200 /* (vipant_ln_qkv_bwd_e4m3) the plan's activation scratch already holds dqkv's e4m3 form (vipant_mha_bwd_e4m3) */
 /* out fp32 [M, D] = x (fp32, or fp16 with VIPANT_STREAM_IN_F16) + add bf16 (the last block's residual add, no norm behind it). */
 int32_t vipant_residual_add(const void* x, const uint16_t* add, float* out, int64_t n, int32_t stream_flags, void* stream);
 /* dx[M,D] = dres (optional residual-stream gradient) + LN'(dy); outputs dx_f32 (optional) and dx_bf16 (optional).
@@ -211,6 +212,19 @@ int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64
 size_t vipant_mx_scale_bytes(int64_t M, int64_t K);
 int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
                              void* stream);
+/* The same for K columns (K % 32 == 0) that start at column 32 * kb0 of rows 128 * kt_row elements long in the scale layout; x and q
+ * point at the first of those columns. */
+int32_t vipant_quant_e4m3_mx_cols(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                  int64_t kt_row, int64_t kb0, void* stream);
+/* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result -- vipant_quant_e4m3_mx of `out`
+ * [M, D] resp. `dqkv` [M, 3 D], bit for bit -- for the contraction that follows (out_proj; in_proj^T).  No reference counterpart
+ * (BASELINE.json configs[4]).  Emitted by the kernels' epilogues where they hold whole blocks (the resident forward: all of `out`;
+ * the streamed single-pass backward: the dK | dV columns), by the stand-alone pass otherwise.  H even (D % 128 == 0). */
+int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float* lse, uint8_t* out_q, uint8_t* out_scale, int64_t batch,
+                            int64_t S, int64_t H, int32_t causal, void* stream);
+int32_t vipant_mha_bwd_e4m3(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta,
+                            uint16_t* dqkv, uint8_t* dqkv_q, uint8_t* dqkv_scale, int64_t batch, int64_t S, int64_t H,
+                            int32_t causal, void* stream);
 /* C[M, N] (bf16) = dequant(A, sa) dequant(B, sb)^T (+ bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation; the scales ride
  * the instruction's block-scale operands).  A [M, K] e4m3: an activation, sa = its BLOCK scales (vipant_quant_e4m3_mx layout); B [N, K]
  * e4m3: a weight matrix, sb = one scale per row (vipant_quant_e4m3_rows).  Epilogues: VIPANT_EPI_BF16, VIPANT_EPI_QUICKGELU_D8,

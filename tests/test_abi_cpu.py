@@ -122,11 +122,15 @@ def test_streamed_attention_backward_does_not_touch_v_fragments_before_their_wai
     path = build.isa_path("attention.hip")
     assert os.path.exists(path), path
     text = open(path).read()
-    m = re.search(r"^(_ZN\S*mha_bwd1s_kernelILi20E\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M)
-    assert m, "mha_bwd1s_kernel<20> not found in the kept assembly"
-    lines = m.group(2).split("\n")
-    waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt\s+vmcnt\(22\)", l)]
-    assert len(waits) == 1, waits
+    found = re.findall(r"^(_ZN\S*mha_bwd1s_kernelILi20ELb([01])E\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M)
+    assert sorted(f[1] for f in found) == ["0", "1"], [f[0] for f in found]       # the plain kernel and the one that also emits e4m3 dK / dV
+    for name, q8, code in found:
+        _check_bwd1s_isa(code.split("\n"), 62 if q8 == "1" else 22)
+
+
+def _check_bwd1s_isa(lines, nwait):
+    waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt\s+vmcnt\(%d\)" % nwait, l)]
+    assert len(waits) == 1, (nwait, waits)
 
     def agprs(line):
         regs = set()
@@ -145,6 +149,9 @@ def test_streamed_attention_backward_does_not_touch_v_fragments_before_their_wai
     assert len(draws) == 1 and group[0] - draws[0] < 60, (draws, group[0])
     loaded |= agprs(lines[draws[0]].split(",")[0])
     assert len(loaded) == 41, sorted(loaded)
+    # between the loads and the counted wait: exactly the stores the count assumes (2 of dQ + 20 of dK / dV [+ 40 e4m3 / scale stores])
+    stores = [i for i in range(group[-1], waits[0]) if re.search(r"^\s*(buffer|global)_store", lines[i])]
+    assert len(stores) == nwait, (nwait, len(stores))
     for i in range(draws[0] + 1, waits[0]):
         if i in group or lines[i].lstrip().startswith(";"):
             continue

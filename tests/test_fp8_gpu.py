@@ -242,6 +242,36 @@ def test_layernorm_fused_block_quantisation_is_the_standalone_one(ops, D):
     assert torch.equal(dxb, dxb2)
 
 
+@pytest.mark.parametrize("batch,S,H,causal", [(3, 316, 12, False), (2, 306, 16, False), (60, 316, 12, False), (2, 77, 8, True),
+                                              (3, 200, 4, False), (1, 428, 4, False), (2, 50, 2, False)])
+def test_attention_fused_block_quantisation_is_the_standalone_one(ops, batch, S, H, causal):
+    """vipant_mha_{fwd,bwd}_e4m3: `out` / `dqkv` are bit for bit those of the plain entry points, and the e4m3 bytes + block scales
+    written beside them are exactly vipant_quant_e4m3_mx of those tensors -- whichever kernel emitted them: the resident forward's
+    epilogue (S <= 384), the streamed backward's dK | dV staging (224 < S <= 320, no mask; 720 problems: with the ticket walk) with the
+    dQ columns by the column-range pass, or the stand-alone pass behind the other kernels (causal backward, S = 200, S = 428)."""
+    D = H * 64
+    M = batch * S
+    qkv = rnd(M, 3 * D, seed=41).to(torch.bfloat16) * 1.5
+    dout = rnd(M, D, seed=42).to(torch.bfloat16) * torch.exp2(torch.randint(-6, 3, (M, 1), device=DEV).float()).to(torch.bfloat16)
+    out0, lse0 = ops.mha_fwd(qkv, batch, S, H, causal)
+    q = torch.full((M, D), 0xAA, dtype=torch.uint8, device=DEV)
+    qs = torch.full((ops.query("vipant_mx_scale_bytes", M, D),), 0xAA, dtype=torch.uint8, device=DEV)
+    out1, lse1 = ops.mha_fwd(qkv, batch, S, H, causal, q8=(q, qs))
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1)
+    q_ref, s_ref = ops.quant_e4m3_mx(out0)
+    assert torch.equal(q, q_ref)
+    assert torch.equal(mx_scales(ops, qs, M, D), mx_scales(ops, s_ref, M, D))
+    d0 = ops.mha_bwd(qkv, out0, dout, lse0, batch, S, H, causal)
+    g = torch.full((M, 3 * D), 0xAA, dtype=torch.uint8, device=DEV)
+    gs = torch.full((ops.query("vipant_mx_scale_bytes", M, 3 * D),), 0xAA, dtype=torch.uint8, device=DEV)
+    d1 = ops.mha_bwd(qkv, out0, dout, lse0, batch, S, H, causal, q8=(g, gs))
+    assert torch.equal(d0, d1)
+    g_ref, gs_ref = ops.quant_e4m3_mx(d0)
+    bad = (g != g_ref).nonzero()
+    assert bad.numel() == 0, (bad[:5].tolist(), int(bad.shape[0]))
+    assert torch.equal(mx_scales(ops, gs, M, 3 * D), mx_scales(ops, gs_ref, M, 3 * D))
+
+
 def test_e4m3_stack_with_recomputed_mlp_is_bit_identical(ops):
     """`running.recompute_mlp` under `running.fp8_gemm`: the backward re-runs the e4m3 c_fc contraction from the saved LayerNorm
     output; same bytes in, same bytes out -- activations and every gradient equal the plain e4m3 run bit for bit."""

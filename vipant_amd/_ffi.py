@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("VIPANT_HIP_LIB") or os.path.join(_HERE, "lib", "libvi
 EPI_BF16, EPI_F32, EPI_RESIDUAL_F32, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_SCALE_F32, EPI_QUICKGELU_D8, EPI_DQUICKGELU_D8 = range(8)
 EPI_FEW_ROWS = 0x100          # VIPANT_EPI_FEW_ROWS: one row per item of a batch (read-out rows): the 64 x 64 split-K kernel
 STREAM_FEW_ROWS = 0x100
+STREAM_ACT_Q = 0x200
 STREAM_IN_F16, STREAM_OUT_F16 = 1, 2          # VIPANT_STREAM_*: precision of the residual stream inside the transformer stack
 LN_DY_F32, LN_DRES_BF16, LN_X_F16 = 1, 2, 4
 
@@ -53,6 +54,8 @@ PROTOTYPES = {
     "vipant_layernorm_bwd": (_i32, [_p, _i32, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _i32, _i64, _i64, _p, _sz, _p]),
     "vipant_mha_fwd": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mha_fwd_e4m3": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
+    "vipant_mha_bwd_e4m3": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_rows_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mha_rows_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_rows_ctx_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
@@ -68,6 +71,7 @@ PROTOTYPES = {
     "vipant_gemm_nt_e4m3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_mx_scale_bytes": (_sz, [_i64, _i64]),
     "vipant_quant_e4m3_mx": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
+    "vipant_quant_e4m3_mx_cols": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "vipant_conv_weight_prep": (_i32, [_p, _p, _i64, _i64, _i64, _i32, _p]),
     "vipant_im2col": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p]),
@@ -133,7 +137,10 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: the HIP hot path is not built (run `python -m vipant_amd.build`); "
                 "there is no CPU fallback")
         handle = C.CDLL(LIB_PATH)
+        older = "VIPANT_HIP_LIB" in os.environ       # an A/B run against another (possibly older) build: its missing entry points fail at use
         for name, (res, args) in PROTOTYPES.items():
+            if older and not hasattr(handle, name):
+                continue
             fn = getattr(handle, name)      # AttributeError here = header / library mismatch
             fn.restype, fn.argtypes = res, args
         _lib = handle

@@ -218,13 +218,39 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
         }
         l = group_sum(l);
         settle(qn0); settle(qn1);          // next block's query fragments have arrived; the stores below drain under its MFMAs
-        if (q < p.S) {
-            const float inv = __frcp_rn(l);
-            bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
+        const float inv = __frcp_rn(l);
+        if (p.oq == nullptr) {
+            if (q < p.S) {
+                bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
-            if (g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
+                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
+            }
+        } else {
+            // also the e4m3 form with one scale per 32 columns (common.h): a head's 64 columns are two blocks, block i = the
+            // accumulators dt = 2 i, 2 i + 1 of the four lanes g = 0..3 that share a query
+            u32x2 ow[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ow[dt] = __builtin_bit_cast(u32x2, f32x4_to_bf16x4(o[dt] * inv));
+            const int64_t row = row_base + (q < p.S ? q : 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float sc;
+                const uint32_t pm = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, ow[2 * i][0]), ow[2 * i][1]), ow[2 * i + 1][0]), ow[2 * i + 1][1]);
+                const uint32_t sb = mx_scale_byte_rows(pm, &sc);
+                if (q < p.S) {
+                    uint8_t* qp = p.oq + row * D + h * 64 + i * 32 + g * 4;
+                    *(int*)qp = mx_pack4_bf16(ow[2 * i][0], ow[2 * i][1], sc);
+                    *(int*)(qp + 16) = mx_pack4_bf16(ow[2 * i + 1][0], ow[2 * i + 1][1], sc);
+                    if (g == 0) p.oq_scale[mx_scale_offset(row, 2 * h + i, D >> 7)] = (uint8_t)sb;
+                }
+            }
+            if (q < p.S) {
+                bf16_t* op = p.out + row * D + h * 64 + g * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) *(u32x2*)(op + dt * 16) = ow[dt];
+            }
         }
+        if (q < p.S && g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
     }
 }
 
@@ -510,7 +536,9 @@ __device__ unsigned long long g_attn_stamps[64];
 // a step later is not safe -- the register allocator may park the "loaded" value elsewhere before the data has arrived -- and a
 // compiler-visible load would be awaited together with every piece in flight.  The O rows and lse words a wave needs for its
 // part of delta / its row constants go to buffers private to the wave: no barrier, only the wave's own wait.
-template <int NT>
+// Q8: dK / dV also leave as e4m3 with one scale per 32 columns (p.gq, p.gq_scale: common.h), quantised from the staged rows at the
+// problem's end -- 40 more stores per wave behind the 22, so the counted wait there becomes vmcnt(62).
+template <int NT, bool Q8 = false>
 __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16, KPW = NT / 4, NU = NT / 2;
@@ -906,6 +934,12 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
     // with an even number per key (conflict-free writes, and a 16-byte chunk stays a chunk).  Waves 0, 1: the dead K image; 2, 3: X.
     {
         const __amdgpu_buffer_rsrc_t rs_dkv = uniform_rsrc(dq_base, (uint32_t)(((int64_t)(p.S - 1) * ld + 2 * D + 64) * 2));
+        // (Q8) the same (batch, head) offset in the e4m3 buffer, one byte per element; the scale buffer whole (its tiled layout mixes rows)
+        const int64_t gq_row0 = (int64_t)(prob / p.H) * p.S;
+        const uint32_t gq_col0 = (uint32_t)(prob % p.H) * 64u;
+        const __amdgpu_buffer_rsrc_t rs_gq = uniform_rsrc(Q8 ? p.gq + (pc.q - p.qkv) : nullptr, Q8 ? (uint32_t)((int64_t)(p.S - 1) * ld + 2 * D + 64) : 0u);
+        const __amdgpu_buffer_rsrc_t rs_gs = uniform_rsrc(Q8 ? p.gq_scale : nullptr,
+                                                          Q8 ? (uint32_t)((((int64_t)p.batch * p.S + 127) >> 7) * ((3 * D) >> 7) * 512) : 0u);
         STAMP(13);
         char* stg = (wave < 2 ? kimg : xbuf) + (wave & 1) * (KPW * 4096);
 #pragma unroll
@@ -926,10 +960,25 @@ __global__ __launch_bounds__(256, 1) void mha_bwd1s_kernel(MhaArgs p) {
                 // rows >= S: redirected out of the descriptor's range and dropped, so that every wave issues exactly 20 stores
                 const uint32_t off = key < p.S ? (uint32_t)(((int64_t)key * ld + D + (c >> 3) * D + (c & 7) * 8) * 2) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dkv, off, 0, 0);
+                if constexpr (Q8) {
+                    // the lane's 8 columns are a quarter of a 32-column block: the quad agrees on the exponent; 8 bytes per lane
+                    // and one scale byte per quad, both as buffer stores so that every lane issues them (dropped when out of range)
+                    const u32x4 w = __builtin_bit_cast(u32x4, v);
+                    float sc;
+                    const uint32_t sb = mx_scale_byte<4>(mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), w[2]), w[3]), &sc);
+                    const uint32_t col = (uint32_t)(D + (c >> 3) * D + (c & 7) * 8);       // inside the problem's rows of [M, 3 D]
+                    const uint32_t offq = key < p.S ? (uint32_t)((int64_t)key * ld) + col : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)mx_pack4_bf16(w[0], w[1], sc), (uint32_t)mx_pack4_bf16(w[2], w[3], sc)},
+                                                          rs_gq, offq, 0, 0);
+                    const uint32_t offs = (key < p.S && (c & 3) == 0)
+                        ? (uint32_t)mx_scale_offset(gq_row0 + key, (int)((gq_col0 + col) >> 5), (3 * D) >> 7) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sb, rs_gs, offs, 0, 0);
+                }
             }
     }
     STAMP(14);
-    // the next problem's V fragments (10 loads) went out before this problem's 2 + 20 stores
+    // the next problem's V fragments (10 loads) went out before this problem's 2 + 20 (Q8: + 40) stores
+    if constexpr (Q8) asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); else
     asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
     if (dyn && tid == 0) *tkw = 2u * gridDim.x + tk_raw;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1281,7 +1330,8 @@ int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
     constexpr int lds = 2 * NT * 16 * 128 + 2 * NT * 16 * 64 + 4 * 8192 + 256 + 4096 + 1024 + 16;
     static DeviceOnce once;
     if (first_on_device(once)) {
-        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_bwd1s_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done_on_device(once);
     }
     const int nprob = a.batch * a.H, cus = device_cus();       // one persistent workgroup per CU
@@ -1292,7 +1342,8 @@ int32_t launch_bwd1s(const MhaArgs& a, hipStream_t s) {
         t.tk = vipant_ticket_block(s, &t.tk_other);
         if (!t.tk) return VIPANT_EHIP;
     }
-    hipLaunchKernelGGL((mha_bwd1s_kernel<NT>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, t);
+    if (t.gq != nullptr) hipLaunchKernelGGL((mha_bwd1s_kernel<NT, true>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, t);
+    else hipLaunchKernelGGL((mha_bwd1s_kernel<NT, false>), dim3(nprob < cus ? nprob : cus), dim3(256), lds, s, t);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
@@ -1348,6 +1399,36 @@ extern "C" int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, cons
     MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv,
               (int)batch, (int)S, (int)H, 0};
     return causal ? dispatch<true, true>(a, (hipStream_t)stream) : dispatch<false, true>(a, (hipStream_t)stream);
+}
+
+// The same two with the e4m3 + MX-scale form of the result beside the bf16 one (BASELINE configs[4]: the out_proj / in_proj^T
+// contractions read it; csrc/block.hip).  The resident forward and the streamed single-pass backward emit it from their
+// epilogues (the backward: the dK | dV columns, which leave through LDS as whole rows; dQ leaves inside the hand-scheduled steps
+// and takes the stand-alone pass, a third of the bytes); every other shape runs the stand-alone pass over the whole result.
+extern "C" int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float* lse, uint8_t* oq, uint8_t* oq_scale, int64_t batch,
+                                       int64_t S, int64_t H, int32_t causal, void* stream) {
+    if (int32_t e = check(qkv, batch, S, H)) return e;
+    VIPANT_REQUIRE(oq != nullptr && oq_scale != nullptr && H % 2 == 0, VIPANT_EBADSHAPE, "mha_fwd_e4m3: need both outputs and an even head count");
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
+    const bool fused = S <= 384;                  // the resident forward (dispatch)
+    if (fused) { a.oq = oq; a.oq_scale = oq_scale; }
+    if (int32_t e = causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream)) return e;
+    if (fused) return VIPANT_OK;
+    return vipant_quant_e4m3_mx(out, H * 64, oq, H * 64, oq_scale, batch * S, H * 64, stream);
+}
+
+extern "C" int32_t vipant_mha_bwd_e4m3(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta,
+                                       uint16_t* dqkv, uint8_t* gq, uint8_t* gq_scale, int64_t batch, int64_t S, int64_t H,
+                                       int32_t causal, void* stream) {
+    if (int32_t e = check(qkv, batch, S, H)) return e;
+    VIPANT_REQUIRE(gq != nullptr && gq_scale != nullptr && H % 2 == 0, VIPANT_EBADSHAPE, "mha_bwd_e4m3: need both outputs and an even head count");
+    MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, const_cast<float*>(lse), (const bf16_t*)dout, delta, (bf16_t*)dqkv,
+              (int)batch, (int)S, (int)H, 0};
+    const int64_t D = H * 64;
+    const bool fused = !causal && S > 224 && S <= 320;         // mha_bwd1s_kernel (launch_bwd)
+    if (fused) { a.gq = gq; a.gq_scale = gq_scale; }
+    if (int32_t e = causal ? dispatch<true, true>(a, (hipStream_t)stream) : dispatch<false, true>(a, (hipStream_t)stream)) return e;
+    return vipant_quant_e4m3_mx_cols(dqkv, 3 * D, gq, 3 * D, gq_scale, batch * S, fused ? D : 3 * D, 3 * D / 128, 0, stream);
 }
 
 #ifdef VIPANT_ATTN_STAMPS

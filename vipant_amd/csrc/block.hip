@@ -90,9 +90,11 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
                                           const vipant_fp8_plan* plan, int32_t stream_flags, void* stream) {
     VIPANT_REQUIRE(M > 0 && D > 0 && D % 64 == 0, VIPANT_EBADSHAPE, "ln_qkv_bwd: bad shape M=%ld D=%ld", (long)M, (long)D);
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE, "ln_qkv_bwd: workspace too small");
-    // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D])
-    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M,
-           D, 3 * D, VIPANT_EPI_BF16, stream));
+    // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D]); VIPANT_STREAM_ACT_Q: vipant_mha_bwd_e4m3 has left dqkv's e4m3 form
+    // in the plan's scratch
+    const bool preq = plan != nullptr && (stream_flags & VIPANT_STREAM_ACT_Q);
+    TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, preq ? plan->act_q : nullptr,
+           preq ? plan->act_scale : nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M, D, 3 * D, VIPANT_EPI_BF16, stream));
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
     TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
     // ln_1 backward + residual-gradient add, in place on the stream gradient (fp32 master + bf16 copy, or bf16 only)
@@ -119,8 +121,11 @@ extern "C" int32_t vipant_gemm_bias_residual_fwd_e4m3(const uint16_t* a, const u
                               stream);
     }
     // the step's form: branch output as bf16; the add happens in the next LayerNorm pass
-    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, nullptr, nullptr, a, w, out, bias, nullptr, M, N, K,
-              VIPANT_EPI_BF16, stream);
+    // (a == NULL with a plan: the producer -- vipant_mha_fwd_e4m3 -- has left the operand's e4m3 form in the plan's scratch)
+    VIPANT_REQUIRE(a != nullptr || plan != nullptr, VIPANT_EBADSHAPE, "gemm_bias_residual_fwd: no operand");
+    const bool preq = plan != nullptr && a == nullptr;
+    return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, preq ? plan->act_q : nullptr,
+              preq ? plan->act_scale : nullptr, a, w, out, bias, nullptr, M, N, K, VIPANT_EPI_BF16, stream);
 }
 
 extern "C" int32_t vipant_gemm_bias_residual_fwd(const uint16_t* a, const uint16_t* w, const float* bias,

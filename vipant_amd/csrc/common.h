@@ -13,6 +13,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_AS __attribute__((address_space(3)))
 #define WAVE 64
@@ -163,11 +164,8 @@ __device__ __forceinline__ uint32_t mx_lane_max_u(uint32_t v) {
     if (NL == 8) v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
     return v;
 }
-// packed |.| maxima of a lane -> the block's scale byte (E8M0) over NL lanes, and the float 2^e the conversion divides by
-template <int NL>
-__device__ __forceinline__ uint32_t mx_scale_byte(uint32_t packed_max, float* scale) {
-    uint32_t m = max(packed_max & 0xFFFFu, packed_max >> 16);
-    m = mx_lane_max_u<NL>(m);
+// the block's maximum |.| as bf16 bits -> its scale byte (E8M0) and the float 2^e the conversion divides by
+__device__ __forceinline__ uint32_t mx_scale_of_max(uint32_t m, float* scale) {
     int e = 0;
     if (m != 0u) {
         e = (int)(m >> 7) - 127 - 8 + ((m & 0x7Fu) > 0x60u ? 1 : 0);
@@ -176,6 +174,20 @@ __device__ __forceinline__ uint32_t mx_scale_byte(uint32_t packed_max, float* sc
     const uint32_t byte = (uint32_t)(e + 127);
     *scale = __uint_as_float(byte ? byte << 23 : 0x00400000u);          // 2^e (2^-127 is a subnormal)
     return byte;
+}
+// packed |.| maxima of a lane -> the block's scale byte over NL adjacent lanes
+template <int NL>
+__device__ __forceinline__ uint32_t mx_scale_byte(uint32_t packed_max, float* scale) {
+    uint32_t m = max(packed_max & 0xFFFFu, packed_max >> 16);
+    m = mx_lane_max_u<NL>(m);
+    return mx_scale_of_max(m, scale);
+}
+// ... over the four lanes l, l + 16, l + 32, l + 48 (an MFMA accumulator's four row groups: the attention epilogues)
+__device__ __forceinline__ uint32_t mx_scale_byte_rows(uint32_t packed_max, float* scale) {
+    uint32_t m = max(packed_max & 0xFFFFu, packed_max >> 16);
+    m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
+    return mx_scale_of_max(m, scale);
 }
 __device__ __forceinline__ int mx_pack4_bf16(uint32_t lo2, uint32_t hi2, float scale) {      // four bf16 (two packed words) -> four e4m3 bytes
     s16x2 w = {0, 0};

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void quant_e4m3_rows_kernel(const bf16_t* __re
 // bf16 rows -> e4m3 with one power-of-two scale per 32 consecutive elements of a row (the MX block format, common.h): a thread takes 8
 // elements, the four threads of a block agree on the exponent through DPP.  Purely streaming: no row-wide reduction.
 __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
-                                                            int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K) {
+                                                            int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K, int kt_row,
+                                                            int kb0) {
     const int cpr = K / 8;                               // 16-byte chunks per row (a multiple of 4)
     const int64_t total = M * cpr;
     const int64_t span = (int64_t)gridDim.x * 256;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __rest
         float sc;
         const uint32_t e = mx_scale_byte<4>(mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), w[2]), w[3]), &sc) - 127u;
         *(int2*)(q + row * ldq + col) = int2{mx_pack4_bf16(w[0], w[1], sc), mx_pack4_bf16(w[2], w[3], sc)};
-        if ((threadIdx.x & 3) == 0) scale[mx_scale_offset(row, col >> 5, K >> 7)] = (uint8_t)(e + 127);
+        if ((threadIdx.x & 3) == 0) scale[mx_scale_offset(row, kb0 + (col >> 5), kt_row)] = (uint8_t)(e + 127);
     }
 }
 
@@ -444,16 +445,25 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __rest
 
 extern "C" size_t vipant_mx_scale_bytes(int64_t M, int64_t K) { return K > 0 && K % 128 == 0 && M > 0 ? mx_scale_bytes(M, K) : 0; }
 
-extern "C" int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
-                                        void* stream) {
-    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+// K columns starting at column 32 kb0 of rows that are 128 kt_row elements long in the scale layout (x, q point at the first of them)
+extern "C" int32_t vipant_quant_e4m3_mx_cols(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                             int64_t kt_row, int64_t kb0, void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && kb0 >= 0 && kb0 * 32 + K <= kt_row * 128, VIPANT_EBADSHAPE,
+                   "quant_e4m3_mx: need K %% 32 == 0 inside a row of 128 kt_row elements (M=%ld K=%ld kt_row=%ld kb0=%ld)", (long)M, (long)K,
+                   (long)kt_row, (long)kb0);
     VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr,
                    VIPANT_EALIGN, "quant_e4m3_mx: misaligned rows");
     const int64_t blocks = ceil_div(M * (K / 8), 256);
     hipLaunchKernelGGL(quant_e4m3_mx_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K);
+                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K, (int)kt_row, (int)kb0);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                        void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+    return vipant_quant_e4m3_mx_cols(x, ldx, q, ldq, scale, M, K, K / 128, 0, stream);
 }
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,

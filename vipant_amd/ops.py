@@ -219,19 +219,29 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean, rstd, gamma, *, dres=
          dbeta.data_ptr(), _ptr(dx_colsum), int(accumulate), M, D, ws.data_ptr(), ws.numel(), _stream())
 
 
-def mha_fwd(qkv: torch.Tensor, batch: int, S: int, H: int, causal: bool):
+def mha_fwd(qkv: torch.Tensor, batch: int, S: int, H: int, causal: bool, q8=None):
+    """q8 = (bytes, block scales): also leave the e4m3 form of `out` there (vipant_quant_e4m3_mx of it, rows of H * 64 bytes)."""
     _need(qkv, BF16, "mha_fwd.qkv")
     out = torch.empty((batch * S, H * 64), dtype=BF16, device=qkv.device)
     lse = torch.empty((batch, H, S), dtype=F32, device=qkv.device)
-    call("vipant_mha_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, S, H, int(causal), _stream())
+    if q8 is not None:
+        call("vipant_mha_fwd_e4m3", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), q8[0].data_ptr(), q8[1].data_ptr(), batch, S, H,
+             int(causal), _stream())
+    else:
+        call("vipant_mha_fwd", qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, S, H, int(causal), _stream())
     return out, lse
 
 
-def mha_bwd(qkv, out, dout, lse, batch: int, S: int, H: int, causal: bool):
+def mha_bwd(qkv, out, dout, lse, batch: int, S: int, H: int, causal: bool, q8=None):
+    """q8 = (bytes, block scales): also leave the e4m3 form of `dqkv` there (rows of 3 * H * 64 bytes)."""
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    call("vipant_mha_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-         dqkv.data_ptr(), batch, S, H, int(causal), _stream())
+    if q8 is not None:
+        call("vipant_mha_bwd_e4m3", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+             dqkv.data_ptr(), q8[0].data_ptr(), q8[1].data_ptr(), batch, S, H, int(causal), _stream())
+    else:
+        call("vipant_mha_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+             dqkv.data_ptr(), batch, S, H, int(causal), _stream())
     return dqkv
 
 
@@ -508,6 +518,8 @@ GRAD_STREAM_F32 = os.environ.get("VIPANT_GRAD_STREAM", "bf16") == "fp32"
 # the last block's one-query attention with the key / value projection folded into the query side (csrc/readout_ctx.hip);
 # 0: project every token to K and V and attend over those (csrc/readout_rows.hip, the round-3 form)
 LAST_BLOCK_CTX = os.environ.get("VIPANT_LAST_BLOCK_CTX", "1") != "0"
+# 0: the e4m3 forms of the attention output and of dqkv by the stand-alone pass instead of the attention kernels' epilogues (A/B)
+ATTN_EMIT = os.environ.get("VIPANT_ATTN_EMIT", "1") != "0"
 
 
 def heads_to_wide(rows: torch.Tensor, w_t_cols: torch.Tensor, out: torch.Tensor, H: int) -> torch.Tensor:
@@ -700,9 +712,11 @@ class BackboneFn(torch.autograd.Function):
                  C.byref(fp8_plan(q_qkv, None, act)) if fp8 else None, sflags(x), st)
             if xs is not None:
                 x = xs
-            o, lse = mha_fwd(qkv, batch, S, H, causal)
-            call("vipant_gemm_bias_residual_fwd_e4m3", o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(), M, D, D,
-                 C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
+            # (e4m3: the attention kernel leaves its output's e4m3 form in the activation scratch; out_proj reads it from there)
+            q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
+            o, lse = mha_fwd(qkv, batch, S, H, causal, q8=q8)
+            call("vipant_gemm_bias_residual_fwd_e4m3", None if q8 else o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(),
+                 M, D, D, C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
             # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
             x1 = new(D, SDT)
             if "gemm_nt" in KERNEL_PROBE:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
@@ -889,12 +903,14 @@ class BackboneFn(torch.autograd.Function):
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
                  M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq)) if fp8 else None, st)
-            dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal)
+            q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
+            dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal, q8=q8)
             call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None, _ffi.STREAM_IN_F16 if x.dtype == F16 else 0, st)
+                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None,
+                 (_ffi.STREAM_IN_F16 if x.dtype == F16 else 0) | (_ffi.STREAM_ACT_Q if q8 else 0), st)
             del dqkv
             for i, v in enumerate(lg.views):
                 grads[12 * l + i] = v
