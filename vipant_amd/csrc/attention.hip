@@ -106,7 +106,8 @@ template <int V> struct Int2 { static constexpr int value = V; };
 
 
 // ------------------------------------------------------------------------------------------- forward
-template <int NT, bool CAUSAL, int NW, int EDGE>
+// Q8 (built for the audio towers' shape, NT = 20 without mask): the epilogue also writes the e4m3 + block-scale form of `out`.
+template <int NT, bool CAUSAL, int NW, int EDGE, bool Q8 = false>
 __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
         l = group_sum(l);
         settle(qn0); settle(qn1);          // next block's query fragments have arrived; the stores below drain under its MFMAs
         const float inv = __frcp_rn(l);
-        if (p.oq == nullptr) {
+        if constexpr (!Q8) {
             if (q < p.S) {
                 bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
 #pragma unroll
@@ -1301,6 +1302,19 @@ int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done_on_device(once);
     }
+    if constexpr (NT == 20 && !CAUSAL) {
+        if (a.oq != nullptr) {
+            static DeviceOnce once8;
+            if (first_on_device(once8)) {
+                VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW, EDGE, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                done_on_device(once8);
+            }
+            hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE, true>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
+            VIPANT_LAUNCH_CHECK();
+            return VIPANT_OK;
+        }
+    }
     hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
@@ -1410,7 +1424,7 @@ extern "C" int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float
     if (int32_t e = check(qkv, batch, S, H)) return e;
     VIPANT_REQUIRE(oq != nullptr && oq_scale != nullptr && H % 2 == 0, VIPANT_EBADSHAPE, "mha_fwd_e4m3: need both outputs and an even head count");
     MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
-    const bool fused = S <= 384;                  // the resident forward (dispatch)
+    const bool fused = !causal && S > 224 && S <= 320;         // mha_fwd_kernel<20, false, ..., Q8> (launch_fwd_nw)
     if (fused) { a.oq = oq; a.oq_scale = oq_scale; }
     if (int32_t e = causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream)) return e;
     if (fused) return VIPANT_OK;
