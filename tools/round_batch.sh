@@ -6,6 +6,10 @@
 #   shadow     tools/comm_shadow.py -> <tag>_comm_shadow.json
 #   prof       rocprofv3 kernel trace of 13 serial steps (2 warm-up + 8 timed + the 3 of bench.py's serial post-pass) + per-shape table -> <tag>_kernel_stats_serial.csv, <tag>_kernel_shapes_serial.txt
 #   pmc        HBM traffic of the dominant kernels (separate --pmc passes) -> <tag>_pmc_traffic.json
+#   ab_prev    this tree against the previous round's (a `git worktree` checked out as _r4 with its own built library), default bench
+#              lines alternating on this box -> <tag>_ab_prev.txt
+#   alone      per-launch tables: ticket vs static walk, attention kernels with / without e4m3 emission -> <tag>_walk_ab.txt, <tag>_attention_alone.txt
+#   soak       200 timed steps of the default bench (ticket counters over ~20 k persistent launches) -> <tag>_bench_soak.json
 set -u
 batch=${1:-tests}; tag=${2:-r5}
 mkdir -p gpurun_out
@@ -26,5 +30,18 @@ case "$batch" in
     timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-full-last-block-check > /dev/null 2> gpurun_out/${tag}_pmc.err
     timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-full-last-block-check > /dev/null 2>> gpurun_out/${tag}_pmc.err
     python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w gpurun_out/${tag}_pmc_traffic.json | tail -40 ;;
+  ab_prev)
+    : > gpurun_out/${tag}_ab_prev.txt
+    for r in 1 2; do
+      for tree in _r4 .; do
+        ( cd $tree && timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-full-last-block-check 2> /dev/null | tail -1 | \
+          python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tree', 'round $r', d['ms_per_step'], 'ms/step', d['roofline']['avg_launch_ms'], 'ms dominant kernel')" ) >> gpurun_out/${tag}_ab_prev.txt
+      done
+    done
+    cat gpurun_out/${tag}_ab_prev.txt ;;
+  alone)
+    timeout 600 python tools/walk_ab.py 21 > gpurun_out/${tag}_walk_ab.txt 2>&1; tail -8 gpurun_out/${tag}_walk_ab.txt
+    timeout 600 python tools/attn_bench.py 40 > gpurun_out/${tag}_attention_alone.txt 2>&1; tail -9 gpurun_out/${tag}_attention_alone.txt ;;
+  soak)   timeout 900 python bench.py --steps 200 --warmup 3 --no-cpu-baseline --no-full-last-block-check > gpurun_out/${tag}_bench_soak.json 2> gpurun_out/${tag}_bench_soak.err; tail -c 400 gpurun_out/${tag}_bench_soak.json ;;
   *) echo "unknown batch $batch"; exit 2 ;;
 esac
