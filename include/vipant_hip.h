@@ -218,9 +218,9 @@ int32_t vipant_quant_e4m3_mx_cols(const uint16_t* x, int64_t ldx, uint8_t* q, in
                                   int64_t kt_row, int64_t kb0, void* stream);
 /* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result -- vipant_quant_e4m3_mx of `out`
  * [M, D] resp. `dqkv` [M, 3 D], bit for bit -- for the contraction that follows (out_proj; in_proj^T).  No reference counterpart
- * (BASELINE.json configs[4]).  Emitted by the kernels' epilogues at the audio towers' shape (224 < S <= 320, no mask: the resident
- * forward writes all of `out`, the streamed single-pass backward the dK | dV columns), by the stand-alone pass otherwise.  H even
- * (D % 128 == 0). */
+ * (BASELINE.json configs[4]).  The streamed single-pass backward (224 < S <= 320, no mask) emits the dK | dV columns from its own
+ * epilogue; everything else -- dQ, the other backward shapes, the forward -- is the stand-alone pass enqueued behind the kernel.
+ * H even (D % 128 == 0). */
 int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float* lse, uint8_t* out_q, uint8_t* out_scale, int64_t batch,
                             int64_t S, int64_t H, int32_t causal, void* stream);
 int32_t vipant_mha_bwd_e4m3(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta,

@@ -246,9 +246,9 @@ def test_layernorm_fused_block_quantisation_is_the_standalone_one(ops, D):
                                               (3, 200, 4, False), (1, 428, 4, False), (2, 50, 2, False)])
 def test_attention_fused_block_quantisation_is_the_standalone_one(ops, batch, S, H, causal):
     """vipant_mha_{fwd,bwd}_e4m3: `out` / `dqkv` are bit for bit those of the plain entry points, and the e4m3 bytes + block scales
-    written beside them are exactly vipant_quant_e4m3_mx of those tensors -- whichever kernel emitted them: at 224 < S <= 320
-    without mask the resident forward's epilogue and the streamed backward's dK | dV staging (720 problems: with the ticket walk) with
-    the dQ columns by the column-range pass; the stand-alone pass behind the other kernels (causal, S = 200, S = 428, S = 50)."""
+    written beside them are exactly vipant_quant_e4m3_mx of those tensors -- whoever wrote them: at 224 < S <= 320 without mask the
+    streamed backward's dK | dV staging (720 problems: with the ticket walk) with the dQ columns by the column-range pass; the
+    stand-alone pass enqueued behind the kernel for the forward and for the other backward shapes (causal, S = 200, S = 428, S = 50)."""
     D = H * 64
     M = batch * S
     qkv = rnd(M, 3 * D, seed=41).to(torch.bfloat16) * 1.5

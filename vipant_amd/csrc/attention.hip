@@ -106,8 +106,7 @@ template <int V> struct Int2 { static constexpr int value = V; };
 
 
 // ------------------------------------------------------------------------------------------- forward
-// Q8 (built for the audio towers' shape, NT = 20 without mask): the epilogue also writes the e4m3 + block-scale form of `out`.
-template <int NT, bool CAUSAL, int NW, int EDGE, bool Q8 = false>
+template <int NT, bool CAUSAL, int NW, int EDGE>
 __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SP = NT * 16;
@@ -219,39 +218,13 @@ __global__ __launch_bounds__(NW * 64, 2) void mha_fwd_kernel(MhaArgs p) {
         }
         l = group_sum(l);
         settle(qn0); settle(qn1);          // next block's query fragments have arrived; the stores below drain under its MFMAs
-        const float inv = __frcp_rn(l);
-        if constexpr (!Q8) {
-            if (q < p.S) {
-                bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
+        if (q < p.S) {
+            const float inv = __frcp_rn(l);
+            bf16_t* op = p.out + (row_base + q) * D + h * 64 + g * 4;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
-            }
-        } else {
-            // also the e4m3 form with one scale per 32 columns (common.h): a head's 64 columns are two blocks, block i = the
-            // accumulators dt = 2 i, 2 i + 1 of the four lanes g = 0..3 that share a query
-            u32x2 ow[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) ow[dt] = __builtin_bit_cast(u32x2, f32x4_to_bf16x4(o[dt] * inv));
-            const int64_t row = row_base + (q < p.S ? q : 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float sc;
-                const uint32_t pm = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, ow[2 * i][0]), ow[2 * i][1]), ow[2 * i + 1][0]), ow[2 * i + 1][1]);
-                const uint32_t sb = mx_scale_byte_rows(pm, &sc);
-                if (q < p.S) {
-                    uint8_t* qp = p.oq + row * D + h * 64 + i * 32 + g * 4;
-                    *(int*)qp = mx_pack4_bf16(ow[2 * i][0], ow[2 * i][1], sc);
-                    *(int*)(qp + 16) = mx_pack4_bf16(ow[2 * i + 1][0], ow[2 * i + 1][1], sc);
-                    if (g == 0) p.oq_scale[mx_scale_offset(row, 2 * h + i, D >> 7)] = (uint8_t)sb;
-                }
-            }
-            if (q < p.S) {
-                bf16_t* op = p.out + row * D + h * 64 + g * 4;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(u32x2*)(op + dt * 16) = ow[dt];
-            }
+            for (int dt = 0; dt < 4; ++dt) *(bf16x4*)(op + dt * 16) = f32x4_to_bf16x4(o[dt] * inv);
+            if (g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
         }
-        if (q < p.S && g == 0) p.lse[((int64_t)b * p.H + h) * p.S + q] = m * SCALE + __logf(l);
     }
 }
 
@@ -1302,19 +1275,6 @@ int32_t launch_fwd_nw(const MhaArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done_on_device(once);
     }
-    if constexpr (NT == 20 && !CAUSAL) {
-        if (a.oq != nullptr) {
-            static DeviceOnce once8;
-            if (first_on_device(once8)) {
-                VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)mha_fwd_kernel<NT, CAUSAL, NW, EDGE, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                done_on_device(once8);
-            }
-            hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE, true>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
-            VIPANT_LAUNCH_CHECK();
-            return VIPANT_OK;
-        }
-    }
     hipLaunchKernelGGL((mha_fwd_kernel<NT, CAUSAL, NW, EDGE>), dim3(a.batch * a.H), dim3(NW * 64), lds, s, a);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
@@ -1416,18 +1376,17 @@ extern "C" int32_t vipant_mha_bwd(const uint16_t* qkv, const uint16_t* out, cons
 }
 
 // The same two with the e4m3 + MX-scale form of the result beside the bf16 one (BASELINE configs[4]: the out_proj / in_proj^T
-// contractions read it; csrc/block.hip).  The resident forward and the streamed single-pass backward emit it from their
-// epilogues (the backward: the dK | dV columns, which leave through LDS as whole rows; dQ leaves inside the hand-scheduled steps
-// and takes the stand-alone pass, a third of the bytes); every other shape runs the stand-alone pass over the whole result.
+// contractions read it; csrc/block.hip).  The streamed single-pass backward emits it from its problem tail for the dK | dV columns,
+// which leave through LDS as whole rows (dQ leaves inside the hand-scheduled steps and takes the stand-alone pass, a third of the
+// bytes); every other backward shape, and the forward, run the stand-alone pass over the whole result.  (The forward's emission was
+// built and measured in round 5 -- bit-identical, 744 -> 985 us at the ViT-L shape against 744 + 197 for kernel + pass: the kernel is
+// issue-bound and its 16-byte row segments make poor stores -- and taken out again; profiles/r5_cfg5_mx.md.)
 extern "C" int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float* lse, uint8_t* oq, uint8_t* oq_scale, int64_t batch,
                                        int64_t S, int64_t H, int32_t causal, void* stream) {
     if (int32_t e = check(qkv, batch, S, H)) return e;
     VIPANT_REQUIRE(oq != nullptr && oq_scale != nullptr && H % 2 == 0, VIPANT_EBADSHAPE, "mha_fwd_e4m3: need both outputs and an even head count");
     MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
-    const bool fused = !causal && S > 224 && S <= 320;         // mha_fwd_kernel<20, false, ..., Q8> (launch_fwd_nw)
-    if (fused) { a.oq = oq; a.oq_scale = oq_scale; }
     if (int32_t e = causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream)) return e;
-    if (fused) return VIPANT_OK;
     return vipant_quant_e4m3_mx(out, H * 64, oq, H * 64, oq_scale, batch * S, H * 64, stream);
 }
 

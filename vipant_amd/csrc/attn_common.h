@@ -19,7 +19,6 @@ struct MhaArgs {
     uint32_t* tk = nullptr;            // ticket counters of the stream (common.h) for the persistent backward; NULL = static walk
     uint32_t* tk_other = nullptr;      // the stream's other counter set, zeroed by this launch
     // e4m3 + MX block scales of the result beside its bf16 form (BASELINE configs[4]: the next contraction's operand, common.h):
-    uint8_t* oq = nullptr; uint8_t* oq_scale = nullptr;        // forward: `out` [M, D]
     uint8_t* gq = nullptr; uint8_t* gq_scale = nullptr;        // backward: `dqkv` [M, 3 D] (the dK | dV columns; dQ by a pass of its own)
 };
 

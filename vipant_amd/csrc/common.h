@@ -182,13 +182,6 @@ __device__ __forceinline__ uint32_t mx_scale_byte(uint32_t packed_max, float* sc
     m = mx_lane_max_u<NL>(m);
     return mx_scale_of_max(m, scale);
 }
-// ... over the four lanes l, l + 16, l + 32, l + 48 (an MFMA accumulator's four row groups: the attention epilogues)
-__device__ __forceinline__ uint32_t mx_scale_byte_rows(uint32_t packed_max, float* scale) {
-    uint32_t m = max(packed_max & 0xFFFFu, packed_max >> 16);
-    m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
-    m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
-    return mx_scale_of_max(m, scale);
-}
 __device__ __forceinline__ int mx_pack4_bf16(uint32_t lo2, uint32_t hi2, float scale) {      // four bf16 (two packed words) -> four e4m3 bytes
     s16x2 w = {0, 0};
     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(w, __builtin_bit_cast(bf16x2, lo2), scale, false);
