@@ -128,7 +128,7 @@ class _BucketedFn(torch.autograd.Function):
         return None, None, v1, v2
 
 
-def _bucket_worker(rank, world, port, out):
+def _bucket_worker(rank, world, port, out, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -137,7 +137,7 @@ def _bucket_worker(rank, world, port, out):
         g = torch.Generator().manual_seed(3)
         x = torch.randn(8, 5, generator=g)
         w1 = torch.nn.Parameter(torch.randn(5, 6, generator=g)); w2 = torch.nn.Parameter(torch.randn(6, 4, generator=g))
-        sync = parallel.GradSync()
+        sync = parallel.GradSync(overlap=overlap)      # "step": the buckets are held back and go out as ONE collective in wait()
         _BucketedFn.apply(x[rank * 4:rank * 4 + 4], sync, w1, w2).sum().backward()
         sync.wait()
         res = [w1.grad.clone(), w2.grad.clone()]
@@ -162,9 +162,12 @@ def _bucket_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_bucket_reduced_inside_backward_reaches_param_grad(tmp_path):
+@pytest.mark.parametrize("overlap", ["block", "step"])
+def test_bucket_reduced_inside_backward_reaches_param_grad(tmp_path, overlap):
+    """`running.comm_overlap`: per-block buckets reduced as they are handed over, or all of a step's buckets concatenated into one
+    collective when the backward is over (two buckets over the same parameters in the siamese case): the same gradients."""
     out = str(tmp_path / "b.pt")
-    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
     g1, g2, s1, s2, lr = torch.load(out)
     g = torch.Generator().manual_seed(3)
     x = torch.randn(8, 5, generator=g)
