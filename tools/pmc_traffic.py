@@ -32,7 +32,7 @@ KERNELS = {      # substring of the rocprofv3 kernel name -> (label, algorithmic
     # round 4: the same attention against the LayerNorm output h1 itself: h1 in (+ probs out); backward: h1 in, dh1 out (+ probs in)
     "rows_ctx_fwd_kernel": ("rows_ctx_fwd_kernel b=512 S=316 H=12", 2 * M * D + 4 * 512 * 12 * 316),
     "rows_ctx_bwd_kernel": ("rows_ctx_bwd_kernel b=512 S=316 H=12", 2 * 2 * M * D + 4 * 512 * 12 * 316),
-    "mha_bwd1s_kernel<20>": ("mha_bwd1s_kernel<20> b=512 S=316 H=12", QKV + 2 * 2 * M * D + QKV + 3 * 4 * 512 * 12 * 316),
+    "mha_bwd1s_kernel<20, false>": ("mha_bwd1s_kernel<20, false> b=512 S=316 H=12", QKV + 2 * 2 * M * D + QKV + 3 * 4 * 512 * 12 * 316),
     "mha_rows_fwd_kernel": ("mha_rows_fwd_kernel b=512 S=316 H=12", 2 * 2 * M * D + 4 * 512 * 12 * 316),
     "mha_rows_bwd_kernel": ("mha_rows_bwd_kernel b=512 S=316 H=12", 4 * 2 * M * D + 4 * 512 * 12 * 316),
 }
