@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 D, L, E, HEADS = 768, 12, 512, 12
-DOMINANT_KERNEL = "gemm_nt_pp_kernel<6, 8, 2, 0, true>"      # c_fc forward + QuickGELU, 8-bit QuickGELU' code (name as rocprofv3 prints it)
+DOMINANT_KERNEL = "gemm_nt_pp_kernel<6, 12, 2, 0, true>"      # c_fc forward + QuickGELU, 8-bit QuickGELU' code (name as rocprofv3 prints it)
 
 
 def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=False):

@@ -20,8 +20,8 @@ from collections import defaultdict
 M, D = 512 * 316, 768
 QKV = 2 * M * 3 * D          # bytes of the packed q|k|v activations (bf16)
 KERNELS = {      # substring of the rocprofv3 kernel name -> (label, algorithmic bytes per launch)
-    "gemm_nt_pp_kernel<6, 8, 2, 0, true>": (f"gemm_nt_pp_kernel<6, 8, 2, 0, true> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
-    "gemm_nt_pp_kernel<7, 10, 2, 0, true>": (f"gemm_nt_pp_kernel<7, 10, 2, 0, true> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
+    "gemm_nt_pp_kernel<6, 12, 2, 0, true>": (f"gemm_nt_pp_kernel<6, 12, 2, 0, true> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
+    "gemm_nt_pp_kernel<7, 12, 2, 0, true>": (f"gemm_nt_pp_kernel<7, 12, 2, 0, true> M={M} N={4 * D} K={D}", 2 * (M * D + 4 * D * D) + 3 * M * 4 * D),
     # fp16 stream rows, bf16 gradient stream: dy (2) + x (2) + dres (2) in, dx (2) out
     "ln_bwd_kernelILi3ELb0ELb1EDF16_": (f"ln_bwd_kernel<3, bf16 dy, bf16 dres, fp16 x> M={M} D={D}", 8 * M * D),
     # fp16 stream in and out: x (2) + add (2) in, x_out (2) + h (2) out

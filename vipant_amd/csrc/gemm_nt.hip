@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // experiment (VAR 7 / 8): column-grouped walk -- the XCDs split into two column groups (each keeps HALF of the weight matrix,
     // meant to stay in its 4 MiB L2) times four row quarters; a workgroup's sequence number then maps to (panel, column) inside
     // its XCD's share.  Needs the full grid of 256 and an even number of column tiles.
-    constexpr bool GROUPED = VAR == 8;
+    constexpr bool GROUPED = VAR == 8 || VAR == 12;
     const int G = gridDim.x;                                   // multiple of 8, <= ntiles rounded up
     const int cg = ntn / 2, ppx = (ntm + 3) / 4;
     const int ntiles = GROUPED ? ((ppx * cg + 31) / 32) * 256 : ntm * ntn;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     };
     // DEEP schedule (VAR 10; intervals by row halves, B fragments kept in registers): a wave owns 16 rows in EACH 64-row half of
     // its group's A stage (two 1-KiB pieces per half), so that a half can be refilled as soon as its interval is over
-    constexpr bool DEEP = VAR == 10;
+    constexpr bool DEEP = VAR == 10 || VAR == 12;
     char* const ldsA2 = smem + grp * (2 * PP_A_STAGE) + wl * 2048;
     const uint32_t waveA2 = (uint32_t)((grp * 128 + wl * 16) * p.lda * ES), halfA = (uint32_t)(64 * p.lda * ES);
     auto fill_a_half = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, int half, uint32_t koff) {
@@ -997,7 +997,7 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     // ticket walk (common.h) when every XCD's queue holds more than the three rounds a workgroup takes statically: the shortest queue
     // of the plain walk is the last one, of the column-grouped walk (VAR 8) the one of the last row quarter
     const int64_t ppx = (ntm + 3) / 4;
-    const int64_t shortest = VAR == 8 ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
+    const int64_t shortest = (VAR == 8 || VAR == 12) ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
                                       : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
     if (CAN_DYN && grid == 256 && shortest > 96 && !(p.dbg & 4194304)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
         p.tk = vipant_ticket_block(stream, &p.tk_other);
@@ -1014,11 +1014,17 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
 
 template <int EPI>
 int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
-    // schedules of the ping-pong kernel: 0 = k-step intervals, 8 = the same on the column-grouped tile walk, 10 = DEEP
+    // schedules of the ping-pong kernel: 0 = k-step intervals, 8 = the same on the column-grouped tile walk, 10 = DEEP, 12 = DEEP on the grouped walk
     if (p.dbg & 131072) return launch_pp_variant<EPI, 10>(p, stream);      // bit 17: DEEP for every launch (A/B)
     const bool groupable = ceil_div(p.N, BN) % 2 == 0 && ceil_div(p.M, BM) * ceil_div(p.N, BN) >= 256;
     // the column-grouped walk is the default of the c_fc launch (853 vs 870-881 us, step -0.27 ms in-box; the QuickGELU' launch of
     // the same shape does not move: profiles/r2_gemm_experiments.md section 9); bit 11 forces it everywhere, bit 12 turns it off
+    // round 5: the two K = 768 launches with 12 column tiles (c_fc + QuickGELU, QuickGELU') run the DEEP schedule ON the column-grouped
+    // walk (variant 12): half of the weight matrix per XCD stays in its L2 (the plain DEEP walk re-streams all of it every round:
+    // QuickGELU' fetched 1.93 GB for 0.75 GB of operands) and the look-ahead of DEEP is kept; 878.9 -> 870.2 us and 883.4 -> 872.2 us,
+    // alternating in one process, bit-identical (tools/grouped_walk_ab.py).  Bit 23 of VIPANT_GEMM_VARIANT: the round-4 choice (8 / 10).
+    if constexpr (EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8)
+        if (groupable && !(p.dbg & (8388608 | 4096 | 2048 | 262144))) return launch_pp_variant<EPI, 12>(p, stream);
     if (groupable && !(p.dbg & 4096) && (EPI == VIPANT_EPI_QUICKGELU_D8 || (p.dbg & 2048))) return launch_pp_variant<EPI, 8>(p, stream);
     // the DEEP schedule (three barrier intervals of look-ahead for every operand piece, intervals by row halves): -2 ... -5 % on the
     // launches with a long K or a wide N (qkv 608-624 -> 589-603 us, QuickGELU' 933-947 -> 916, dh2 627-634 -> 596-604), +3 % on the
