@@ -1025,6 +1025,9 @@ int32_t launch_pp(const GemmNT& p, hipStream_t stream) {
     // alternating in one process, bit-identical (tools/grouped_walk_ab.py).  Bit 23 of VIPANT_GEMM_VARIANT: the round-4 choice (8 / 10).
     if constexpr (EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8)
         if (groupable && !(p.dbg & (8388608 | 4096 | 2048 | 262144))) return launch_pp_variant<EPI, 12>(p, stream);
+    // ... and plain launches with >= 8 column tiles (no shape of the ViT-B step: qkv has 9; the ViT-L qkv launch has 12)
+    if constexpr (EPI == VIPANT_EPI_BF16)
+        if (groupable && ceil_div(p.N, BN) >= 8 && !(p.dbg & (8388608 | 4096 | 2048 | 262144))) return launch_pp_variant<EPI, 12>(p, stream);
     if (groupable && !(p.dbg & 4096) && (EPI == VIPANT_EPI_QUICKGELU_D8 || (p.dbg & 2048))) return launch_pp_variant<EPI, 8>(p, stream);
     // the DEEP schedule (three barrier intervals of look-ahead for every operand piece, intervals by row halves): -2 ... -5 % on the
     // launches with a long K or a wide N (qkv 608-624 -> 589-603 us, QuickGELU' 933-947 -> 916, dh2 627-634 -> 596-604), +3 % on the
@@ -1326,6 +1329,10 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
     switch (epilogue) {
         case VIPANT_EPI_BF16:
             // the deep look-ahead schedule (VAR 10): -2..-4 % at K >= 3072, neutral at K <= 1024; bit 15 of VIPANT_GEMM_VARIANT: off
+            // wide outputs (>= 8 column tiles, an even number): DEEP on the column-grouped walk -- the ViT-L qkv launch (N = 3072, K = 1024)
+            // 1172 -> 1133 us, bit-identical; at N = 1024 (four column tiles) it gains nothing or loses.  Bit 26: off.
+            if (!(fp8_dbg & (67108864 | 32768)) && ceil_div(M, BM) * ceil_div(N, BN) >= 256 && ceil_div(N, BN) % 2 == 0 && ceil_div(N, BN) >= 8)
+                return launch_pp_variant<VIPANT_EPI_BF16, 12, 1>(p, s);
             if (!(fp8_dbg & 32768)) return launch_pp_variant<VIPANT_EPI_BF16, 10, 1>(p, s);
             return launch_pp_variant<VIPANT_EPI_BF16, 0, 1>(p, s);
         case VIPANT_EPI_QUICKGELU_D8:
@@ -1338,9 +1345,16 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
             }
             if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C == nullptr)
                 return launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 2>(p, s);           // the e4m3 form alone
-            if (cq != nullptr)
+            if (cq != nullptr) {
+                // the column-grouped walk (k-step schedule; half of the weight bytes per XCD): 2186 -> 2149 us and 2329 -> 2305 us at the
+                // ViT-L shape, bit-identical; DEEP on the grouped walk gains nothing here.  Bit 25 of VIPANT_GEMM_VARIANT: the plain walk.
+                const bool groupable = ceil_div(M, BM) * ceil_div(N, BN) >= 256 && ceil_div(N, BN) % 2 == 0;
+                if (groupable && !(fp8_dbg & 33554432))
+                    return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 8, 1, 1>(p, s)
+                                                                : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 8, 1, 1>(p, s);
                 return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 1>(p, s)
                                                             : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1, 1>(p, s);
+            }
             return epilogue == VIPANT_EPI_QUICKGELU_D8 ? launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1>(p, s)
                                                         : launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1>(p, s);
         default:
