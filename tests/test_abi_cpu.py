@@ -157,3 +157,34 @@ def _check_bwd1s_isa(lines, nwait):
             continue
         hit = agprs(lines[i]) & loaded
         assert not hit, (i, lines[i].strip(), sorted(hit))
+
+
+def test_ticket_walk_mailbox_register_is_never_copied():
+    """Round 5: every wave of a ticket-walk NT kernel requests its mailbox word with an inline-asm `global_load_dword` BEHIND a tile's
+    epilogue stores and reads the register in the next tile's bias round trip, after at least three K-tiles of hand-counted vmcnt waits
+    (csrc/gemm_nt.hip; the read is pinned there by a volatile asm).  The compiler does not know the load is in flight: if it ever
+    relocated that register in between (a move, a spill to scratch / an AGPR / a lane), a workgroup would walk a stale tile index.
+    Checked on the shipped build's assembly, for every ticket instantiation: one asm load; in program text the register's last mention
+    is that load (the loop's back edge follows); it is read by a `v_readfirstlane_b32`; and no instruction anywhere COPIES it (the
+    allocator may reuse the register as an arithmetic temporary between the read and the next load)."""
+    from vipant_amd import build
+    build.build(verbose=False)
+    path = build.isa_path("gemm_nt.hip")
+    assert os.path.exists(path), path
+    text = open(path).read()
+    kernels = re.findall(r"^(_ZN\S*gemm_nt_pp_kernelILi\d+ELi\d+ELi2ELi0ELb1E\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) >= 8, len(kernels)
+    for name, code in kernels:
+        lines = [l.split(";")[0] for l in code.split("\n")]
+        raw = code.split("\n")
+        loads = [i for i, l in enumerate(lines) if re.match(r"\s*global_load_dword\s+v\d+,\s*v\[\d+:\d+\],\s*off\s*$", l)
+                 and "ASMSTART" in raw[i - 1]]
+        assert len(loads) == 1, (name, loads)
+        reg = re.match(r"\s*global_load_dword\s+(v\d+),", lines[loads[0]]).group(1)
+        uses = [i for i, l in enumerate(lines) if re.search(r"\b%s\b" % reg, l)]
+        assert uses[-1] == loads[0], (name, reg, [lines[i].strip() for i in uses[-3:]])
+        assert any(re.match(r"\s*v_readfirstlane_b32\s+s\d+,\s*%s\b" % reg, lines[i]) for i in uses), (name, reg)
+        copies = [lines[i].strip() for i in uses
+                  if re.match(r"\s*(v_mov_b32_e32\s+v\d+|v_accvgpr_write_b32\s+a\d+|v_writelane_b32\s+v\d+),\s*%s\b" % reg, lines[i])
+                  or re.match(r"\s*(scratch_store|global_store|buffer_store|ds_write)\S*\s.*\b%s\b" % reg, lines[i])]
+        assert not copies, (name, reg, copies)

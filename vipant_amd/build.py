@@ -37,7 +37,7 @@ EXTRA_CFLAGS = {"gemm_nt.hip": ["-mllvm", "-disable-machine-sink", "-mllvm", "-a
 # files whose device assembly is kept beside the object (lib/obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s): kernels with hand-counted
 # `s_waitcnt vmcnt(n)` or inline-asm loads, whose correctness depends on what the compiler put between two instructions
 # (tests/test_abi_cpu.py reads it)
-KEEP_ISA = ("attention.hip",)
+KEEP_ISA = ("attention.hip", "gemm_nt.hip")
 
 
 def isa_path(name: str) -> str:

@@ -602,15 +602,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     const int lane_pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (lane_pos >= ntiles) return;                            // whole workgroup: no barrier has been executed yet
     const int nk = p.K / (ES == 2 ? BK : 2 * BK);
-    // Ticket walk (common.h; the host sets p.tk only for a full grid whose every queue is longer than three rounds).  A workgroup's
-    // first three tiles are the static walk's (positions b >> 3, + 32, + 64 of queue b & 7: nothing to wait for at start-up); from
-    // the fourth on, positions come from the queue's counter.  The stream needs a tile's successor one tile ahead, the LDS is full
-    // and `vmcnt` retires in order (anything slow in front of the counted LDS-DMA waits stalls them), so a ticket travels without a
-    // wait of its own: wave 0 draws it at the START of an epilogue (the atomic has the whole epilogue to return), holds it until
-    // the next tile's bias round trip (the one full wait a tile has anyway: the value is there), writes it to the workgroup's
-    // mailbox (two words, alternating), and every wave reads that word in the bias round trip of the tile after that.  A workgroup
-    // therefore holds claims on three tiles beyond the one it computes.  (gemm_nt.hip is compiled with the atomic optimizer off:
-    // it turns a uniform atomic into "first lane adds, wait, broadcast" -- a full wait where the draw is issued.)
+    // Ticket walk (common.h; the host sets p.tk only for a full grid whose every queue is longer than four rounds, K >= 256).  A
+    // workgroup's first four tiles are the static walk's (positions b >> 3, + 32, + 64, + 96 of queue b & 7: nothing to wait for at
+    // start-up); from the fifth on, positions come from the queue's counter.  The stream needs a tile's successor one tile ahead, the
+    // LDS is full and `vmcnt` retires in order (anything slow in front of the counted LDS-DMA waits stalls them), so a ticket travels
+    // without a wait of its own, through the three places of a tile where one is free:
+    //   1. thread 0 draws it at the START of an epilogue (the atomic has the whole epilogue to return);
+    //   2. in the next tile's bias round trip (the one full wait a tile has anyway: the value is there) it becomes a tile index, and
+    //      thread 0 stores that into the workgroup's mailbox (two words in global memory, alternating) at the start of THAT
+    //      tile's epilogue, in front of the tile's own stores;
+    //   3. one epilogue later every wave requests the word BEHIND its tile's stores (asm load: the counted waits of the next K-loop
+    //      retire those stores and the load with them) and reads the register in that tile's bias round trip: a scalar from there,
+    //      `tile_nn`, the tile after the next, described one epilogue later.
+    // A workgroup therefore holds claims on four tiles beyond the one it computes.  (First form, same round: the word was read with
+    // an ordinary load inside the K-loop, two K-tiles before the tile's end -- a load there has one barrier interval to return,
+    // and the loop got a second peeled K-tile: +3 ... +17 us per launch, gone with this form except on QuickGELU', see the draw.)
+    // (gemm_nt.hip is compiled with the atomic optimizer off: it turns a uniform atomic into "first lane adds, wait, broadcast" -- a
+    // full wait where the draw is issued.)
     // All of the walk's state lives in VECTOR registers on purpose (the `"+v"` launderings below): the K-loop keeps ~100 scalars busy
     // with buffer descriptors and offsets, and a dozen more made hipcc spill 27 of them into VGPR lanes -- 70 v_readlane / v_writelane
     // and 290 hazard s_nops in the loop: +5 % on the c_fc launch, whichever walk ran (round 5, same-box A/B against the round-4 tree).
@@ -634,19 +642,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         tkq = (uint64_t)(p.tk + xq);
         asm volatile("" : "+v"(xq), "+v"(qlen_own), "+v"(mbox), "+v"(tkq));
     }
-    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 96 + value)
+    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 128 + value)
     int tk_dry = 0;                             // thread 0: the queue is empty, stop drawing
     int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
     int tk_first = 1;                           // the first tile's round trip has nothing to read: its "ticket" is the third static tile
     if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first));
     auto tk_tile = [&](uint32_t drawn) {
-        const int pos = 96 + (int)drawn;
+        const int pos = 128 + (int)drawn;
         if (pos < qlen_own) return tickets::tile_of(xq, pos);
         tk_dry = 1;
         return NO_TILE;
     };
     if (dyn && tid == 0) {
-        tk_pend = tickets::take_g(tkq);         // this workgroup's fourth tile; not awaited before the first tile's bias round trip
+        tk_pend = tickets::take_g(tkq);         // this workgroup's fifth tile; not awaited before the first tile's bias round trip
         // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
         // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
         if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
@@ -850,11 +858,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();         // the lag: group 1 runs one barrier interval behind group 0
 
-    // (tk_next, tk_post: the destination of the mailbox load and the data register of the mailbox store live across the whole walk --
-    // the kernel's last statement reads them.  hipcc protects a register that a load / store in flight still names with a vmcnt wait
-    // in front of its next writer: a wait behind LDS-DMA pieces or code loads wherever the allocator happened to reuse it.)
-    uint32_t tk_next = 0u, tk_post = 0u;
-    int tk_next_s = NO_TILE;
+    // (tk_post, the data register of the mailbox store, lives across the whole walk -- the kernel's last statement reads it.  hipcc
+    // protects a register that a store in flight still names with a vmcnt wait in front of its next writer: a wait behind LDS-DMA
+    // pieces or code loads wherever the allocator happened to reuse it.)
+    uint32_t tk_post = 0u;
+    uint32_t tk_raw = 0u;                       // the mailbox word in flight (asm load; read only behind the next K-tile 0's counted waits)
+    bool tk_defer = false;
+    int tile_nn = tile_nxt + G;                 // the tile after `tile_nxt` (ticket walk: static for a workgroup's first four tiles)
     while (tile < ntiles) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -866,10 +876,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         for (int k = 0; k < nk; ++k) {
             const int stage = gk & 1;
             const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-            // the ticket of the tile after the next: read one K-tile ahead of the bias round trip, which then finds it landed (a CU's
-            // memory pipeline is in order: read IN that round trip, the load waits behind the DMA pieces in flight, +0.9 us per
-            // tile on the launches without a bias)
-            if (dyn && k == nk - 2) tk_next = tickets::peek_g(mbox + 4 * tk_par);
             if (k == nk - 1) {                   // the tile's bias: fetched and awaited before this K-tile's DMA is queued
                 load_bias<EPI>(p, cur.n0, wl, fq, bv);
                 if (ES == 1) load_b_scales(nxt, sbv_n);                       // the next tile's weight scales ride the same round trip
@@ -880,6 +886,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
                     tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
                     tk_par ^= 1;                 // (the store itself goes out at the start of the epilogue, in front of the tile's own stores)
+                    // the mailbox word requested behind the previous epilogue (asm load, see there): nk - 1 >= 3 K-tiles of counted
+                    // waits have retired it.  It names the tile after `tile_nxt`; a scalar from here.
+                    asm volatile("" : "+v"(tk_raw));
+                    const int drawn = __builtin_amdgcn_readfirstlane((int)tk_raw);
+                    tile_nn = tk_defer ? drawn : tile_nn;
                     asm volatile("" : "+v"(tk_par));
                 }
                 // (issued behind the waits above -- the code bytes come from HBM -- and not awaited here)
@@ -949,11 +960,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             ++gk;
             slot = slot1;
             if (ES == 1) { sav[0] = sav_n[0]; sav[1] = sav_n[1]; }
-            // the ticket read at the top of this K-tile is older than the K-tile's eight pieces: the counted wait that ended it has
-            // retired it, and in straight-line code hipcc's own wait for it is that same vmcnt(8) -- not the vmcnt(0) it puts in
-            // front of a use one iteration later (which, on the launches without a bias, waited for every piece in flight: +58 us
-            // on the QuickGELU' launch).  From here the ticket is a scalar.
-            if (dyn && k == nk - 2) tk_next_s = __builtin_amdgcn_readfirstlane((int)tk_next);
         }
         // epilogue: 4 rounds of 32 rows through the A stage this group's stream does not use (the one just read)
         char* stg = smem + grp * (2 * PP_A_STAGE) + ((gk - 1) & 1) * PP_A_STAGE;
@@ -961,20 +967,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // the mailbox store goes here and not next to the bias: there it was the first operation behind a full wait, and the next
         // counted wait -- which lets the K-tile's eight pieces stay in flight -- had to see its acknowledgement first (+0.5 us per tile
         // on the launches with a bias); here the tile's own stores queue up behind it and nobody waits for it in particular
+        // (What the draw still costs, round 5, bits switched off one by one in a test build: nothing measurable on the launches whose
+        // epilogue only stores; 10-25 us per launch on QuickGELU', whose epilogue waits for its code loads every round -- vmcnt retires
+        // in order, so thread 0's wave sees those loads only when the atomic, a ~2 us round trip, is back too, wherever in the
+        // epilogue it is issued, and the other waves meet it at the round's barrier.)
         if (dyn && tid == 0) {
             tickets::post_g(mbox + 4 * tk_par, tk_post);
             if (!tk_dry) tk_pend = tickets::take_g(tkq);      // not awaited here
         }
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
+        // Every wave requests the word posted ONE epilogue ago (the other parity): the index of the tile after the next.  The request
+        // is inline asm: a load hipcc can see would be awaited where it is first used with a wait it cannot count (the epilogue's stores
+        // sit behind bounds checks: it would be vmcnt(0), every store's acknowledgement), and anywhere inside the K-loop a load has one
+        // barrier interval to return (that was the first form: read at K-tile nk - 2, +0.5 us per tile on several launches).  Issued
+        // here, behind the tile's stores, it costs no wait of its own: the counted waits of the next K-tile 0 retire those stores anyway
+        // and the load with them (it is older than that K-tile's eight pieces); only then is the register read.  (An accumulation
+        // register as destination is not affordable: one AGPR costs a granule of eight registers and the K-loop spills.)
+        if (dyn) asm volatile("global_load_dword %0, %1, off" : "=&v"(tk_raw) : "v"(mbox + 4 * (tk_par ^ 1)) : "memory");
         tile = tile_nxt;
-        tile_nxt = (dyn && !__builtin_amdgcn_readfirstlane(tk_first)) ? tk_next_s : tile_nxt + G;
-        if (DYN) { tk_first = 0; asm volatile("" : "+v"(tk_first)); }
         cur = nxt;
+        if (dyn) {
+            // the word requested above is this tile's successor's SUCCESSOR's successor: it becomes `tile_nn` at the end of the new
+            // tile's K-tile 0 (one scalar; describing a tile costs registers the K-loop does not have) and `nxt` one epilogue later
+            tile_nxt = tile_nn;
+            tk_defer = !__builtin_amdgcn_readfirstlane(tk_first);
+            if (!tk_defer) tile_nn = tile_nxt + G;          // after the first epilogue nothing has been posted yet: the fourth static tile
+        } else {
+            tile_nxt = tile_nxt + G;
+        }
         nxt = describe(tile_nxt);
+        if (DYN) { tk_first = 0; asm volatile("" : "+v"(tk_first)); }
         if (ES == 1) sbv = sbv_n;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with group 1's last barrier
-    if (dyn && (tk_next ^ tk_post) == 0xA5A5A5A5u) tickets::post_g(mbox, tk_next);       // never true (tickets are < 2^30): the keep-alive
+    if (dyn && tk_post == 0xA5A5A5A5u) tickets::post_g(mbox, tk_post);       // never true (tickets are < 2^30): keeps the store's data register
 }
 
 template <int EPI, int VAR, int ES = 2, int EMIT = 0>
@@ -999,7 +1025,7 @@ int32_t launch_pp_variant(const GemmNT& p_in, hipStream_t stream) {
     const int64_t ppx = (ntm + 3) / 4;
     const int64_t shortest = (VAR == 8 || VAR == 12) ? (ntm - 3 * ppx > 0 ? (ntm - 3 * ppx < ppx ? ntm - 3 * ppx : ppx) : 0) * (ntn / 2)
                                       : (tiles >> 8) * 32 + ((tiles & 255) > 224 ? (tiles & 255) - 224 : 0);
-    if (CAN_DYN && grid == 256 && shortest > 96 && !(p.dbg & 4194304)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
+    if (CAN_DYN && grid == 256 && shortest > 128 && p.K >= 4 * BK && !(p.dbg & 4194304)) {      // bit 22 of VIPANT_GEMM_VARIANT: static walk (A/B)
         p.tk = vipant_ticket_block(stream, &p.tk_other);
         if (p.tk == nullptr) return VIPANT_EHIP;
         hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, VAR, ES, EMIT, CAN_DYN>), dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, stream, p);
