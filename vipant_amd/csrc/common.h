@@ -190,27 +190,18 @@ __device__ __forceinline__ int mx_pack4_bf16(uint32_t lo2, uint32_t hi2, float s
 }
 
 namespace tickets {
-__device__ __forceinline__ uint32_t take(uint32_t* p, uint32_t n = 1u) {
-    return __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void put(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// the mailbox is written and read by waves of ONE workgroup (one CU, one vector L1, which is write-through): plain accesses, ordered
-// by the writer's vmcnt wait and a workgroup barrier.  Measured on a 870 us launch of 30 tiles per workgroup, one load per tile:
-// agent scope (L1 bypass) +45 us, workgroup scope (sc0) +3-8 us on the launches whose tile has no other load to wait for.
-// (wavefront-scope relaxed atomics = plain global_load / global_store without cache-policy bits; `volatile` would make them
-// system-scope flat accesses)
-__device__ __forceinline__ void post(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-__device__ __forceinline__ uint32_t peek(const uint32_t* p) {
-    return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-// the same three on a GLOBAL address carried as an integer in vector registers (a pointer laundered through `asm("" : "+v")` loses its
-// address space: hipcc then emits flat accesses, which wait on vmcnt AND lgkmcnt and make it put vmcnt(0) in front of LDS reads)
+// The draw and the mailbox store on a GLOBAL address carried as an integer in vector registers (a pointer laundered through
+// `asm("" : "+v")` loses its address space: hipcc then emits flat accesses, which wait on vmcnt AND lgkmcnt and make it put vmcnt(0) in
+// front of LDS reads).  The mailbox is written and read by waves of ONE workgroup (one CU, one vector L1): plain accesses --
+// wavefront-scope relaxed atomics are `global_store` / `global_load` without cache-policy bits (`volatile` would make them
+// system-scope flat accesses; an agent-scope read, which bypasses the L1, cost +45 us on a 870 us launch) -- ordered by their
+// distance: the store goes out at the start of an epilogue, the word is read behind the NEXT epilogue's stores (csrc/gemm_nt.hip).
 typedef __attribute__((address_space(1))) uint32_t gu32_t;
 __device__ __forceinline__ uint32_t take_g(uint64_t a) {
     return __hip_atomic_fetch_add((gu32_t*)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void post_g(uint64_t a, uint32_t v) { __hip_atomic_store((gu32_t*)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-__device__ __forceinline__ uint32_t peek_g(uint64_t a) { return __hip_atomic_load((gu32_t*)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 // position s of queue q -> the tile the static walk of a 256-workgroup grid gave workgroup q + 8 (s & 31) in its round s >> 5
 __device__ __forceinline__ int tile_of(int q, int s) { return (s >> 5) * 256 + q * 32 + (s & 31); }
 }  // namespace tickets
