@@ -198,8 +198,8 @@ __device__ __forceinline__ void put(uint32_t* p, uint32_t v) { __hip_atomic_stor
 // system-scope flat accesses; an agent-scope read, which bypasses the L1, cost +45 us on a 870 us launch) -- ordered by their
 // distance: the store goes out at the start of an epilogue, the word is read behind the NEXT epilogue's stores (csrc/gemm_nt.hip).
 typedef __attribute__((address_space(1))) uint32_t gu32_t;
-__device__ __forceinline__ uint32_t take_g(uint64_t a) {
-    return __hip_atomic_fetch_add((gu32_t*)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ uint32_t take_g(uint64_t a, uint32_t n) {     // n consecutive positions per draw
+    return __hip_atomic_fetch_add((gu32_t*)a, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void post_g(uint64_t a, uint32_t v) { __hip_atomic_store((gu32_t*)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 // position s of queue q -> the tile the static walk of a 256-workgroup grid gave workgroup q + 8 (s & 31) in its round s >> 5

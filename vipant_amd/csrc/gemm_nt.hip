@@ -642,11 +642,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         tkq = (uint64_t)(p.tk + xq);
         asm volatile("" : "+v"(xq), "+v"(qlen_own), "+v"(mbox), "+v"(tkq));
     }
-    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (position = 128 + value)
+    uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (positions 128 + value and 128 + value + 1)
+    // the two launches with 30 tiles per workgroup (c_fc + QuickGELU, QuickGELU') take TWO positions per draw, i.e. every other epilogue
+    // issues no atomic: QuickGELU' pays for each one (see the draw), and with queues that long the coarser claim costs nothing
+    // (measured: QuickGELU' +18 -> +6 us against its static twin, c_fc -10; the short-queue launches -- 7 to 22 tiles per
+    // workgroup -- lose 8-12 us with pairs and keep single draws)
+    constexpr bool DRAW2 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
+    int tk_half = 0;                            // thread 0 (DRAW2): the draw's second position is still to be used
     int tk_dry = 0;                             // thread 0: the queue is empty, stop drawing
     int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
     int tk_first = 1;                           // the first tile's round trip has nothing to read: its "ticket" is the third static tile
-    if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first));
+    if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first), "+v"(tk_half));
     auto tk_tile = [&](uint32_t drawn) {
         const int pos = 128 + (int)drawn;
         if (pos < qlen_own) return tickets::tile_of(xq, pos);
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         return NO_TILE;
     };
     if (dyn && tid == 0) {
-        tk_pend = tickets::take_g(tkq);         // this workgroup's fifth tile; not awaited before the first tile's bias round trip
+        tk_pend = tickets::take_g(tkq, DRAW2 ? 2u : 1u);       // this workgroup's fifth (and sixth) tile; not awaited before the first tile's bias round trip
         // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
         // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
         if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
@@ -884,7 +890,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 if (ES == 1) asm volatile("" : "+v"(sbv_n));
                 if (dyn) {
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
-                    tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend));
+                    tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend + (uint32_t)tk_half));
+                    if (DRAW2) tk_half ^= 1;     // (1: the second position of this draw is next, the coming epilogue draws nothing)
                     tk_par ^= 1;                 // (the store itself goes out at the start of the epilogue, in front of the tile's own stores)
                     // the mailbox word requested behind the previous epilogue (asm load, see there): nk - 1 >= 3 K-tiles of counted
                     // waits have retired it.  It names the tile after `tile_nxt`; a scalar from here.
@@ -973,7 +980,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue it is issued, and the other waves meet it at the round's barrier.)
         if (dyn && tid == 0) {
             tickets::post_g(mbox + 4 * tk_par, tk_post);
-            if (!tk_dry) tk_pend = tickets::take_g(tkq);      // not awaited here
+            if (!tk_dry && !tk_half) tk_pend = tickets::take_g(tkq, DRAW2 ? 2u : 1u);      // not awaited here
         }
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         // Every wave requests the word posted ONE epilogue ago (the other parity): the index of the tile after the next.  The request
