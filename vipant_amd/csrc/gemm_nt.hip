@@ -643,10 +643,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         asm volatile("" : "+v"(xq), "+v"(qlen_own), "+v"(mbox), "+v"(tkq));
     }
     uint32_t tk_pend = 0u;                      // thread 0: the counter value of the last draw (positions 128 + value and 128 + value + 1)
-    // the two launches with 30 tiles per workgroup (c_fc + QuickGELU, QuickGELU') take TWO positions per draw, i.e. every other epilogue
-    // issues no atomic: QuickGELU' pays for each one (see the draw), and with queues that long the coarser claim costs nothing
-    // (measured: QuickGELU' +18 -> +6 us against its static twin, c_fc -10; the short-queue launches -- 7 to 22 tiles per
-    // workgroup -- lose 8-12 us with pairs and keep single draws)
+    // the two launches with 30 tiles per workgroup (c_fc + QuickGELU, QuickGELU') take TWO CONSECUTIVE positions per draw: QuickGELU'
+    // +18 -> +7 ... +13 us against its static twin, c_fc 10-18 us FASTER than its static twin (three runs, two boxes).  It is not the
+    // halved number of atomics that pays: pairing positions p and p + 32 (the same workgroup's tiles of two rounds of the static walk,
+    // still one atomic per two tiles) gives the single-draw times back.  Consecutive positions are neighbouring column tiles of ONE
+    // row tile; computed one after the other by one workgroup instead of side by side by two, the A rows are fetched twice (+0.2 GB
+    // per launch in the PMC counters) but the 32 workgroups of a queue spread over twice as many A row tiles at any moment --
+    // fewer workgroups pulling the same lines out of the L2 at the same time.  The short-queue launches (7 to 22 tiles per
+    // workgroup) lose 8-12 us with pairs -- a coarser claim at the end of a short queue -- and keep single draws.
     constexpr bool DRAW2 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
     int tk_half = 0;                            // thread 0 (DRAW2): the draw's second position is still to be used
     int tk_dry = 0;                             // thread 0: the queue is empty, stop drawing
