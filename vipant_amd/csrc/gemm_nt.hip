@@ -649,7 +649,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // still one atomic per two tiles) gives the single-draw times back.  Consecutive positions are neighbouring column tiles of ONE
     // row tile; computed one after the other by one workgroup instead of side by side by two, the A rows are fetched twice (+0.2 GB
     // per launch in the PMC counters) but the 32 workgroups of a queue spread over twice as many A row tiles at any moment --
-    // fewer workgroups pulling the same lines out of the L2 at the same time.  Runs of three consecutive positions are slower again (+10 ... +18 us), runs of six (a workgroup
+    // fewer workgroups pulling the same lines out of the L2 at the same time.  (Walking the queue in column PHASES -- all rows for three, two or one of the six columns, then the
+    // next -- spreads the workgroups the same way with single draws and loses 25-60 us: the A rows come back from HBM a phase later, not from the
+    // caches 27 us later.)  Runs of three consecutive positions are slower again (+10 ... +18 us), runs of six (a workgroup
     // takes a whole row of column tiles) by 90-115 us.  The short-queue launches (7 to 22 tiles per workgroup) lose 8-12 us with pairs -- a
     // coarser claim at the end of a short queue -- and keep single draws.
     constexpr bool DRAW2 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
