@@ -184,7 +184,13 @@ def test_ticket_walk_mailbox_register_is_never_copied():
         uses = [i for i, l in enumerate(lines) if re.search(r"\b%s\b" % reg, l)]
         assert uses[-1] == loads[0], (name, reg, [lines[i].strip() for i in uses[-3:]])
         assert any(re.match(r"\s*v_readfirstlane_b32\s+s\d+,\s*%s\b" % reg, lines[i]) for i in uses), (name, reg)
-        copies = [lines[i].strip() for i in uses
+        # a copy / spill of the register is a violation unless the allocator has given the register a NEW value first (a write to it,
+        # other than the pre-loop zero, earlier in program text: the loop body runs from the bias round trip's read to the asm load)
+        init = [i for i in uses if re.match(r"\s*v_mov_b32_e32\s+%s,\s*0\s*$" % reg, lines[i])]
+        writes = [i for i in uses if i not in init and i != loads[0] and re.match(r"\s*v_\w+\s+%s\b" % reg, lines[i])
+                  and not re.match(r"\s*v_(cmp|readfirstlane|readlane)", lines[i])]
+        copies = [i for i in uses
                   if re.match(r"\s*(v_mov_b32_e32\s+v\d+|v_accvgpr_write_b32\s+a\d+|v_writelane_b32\s+v\d+),\s*%s\b" % reg, lines[i])
                   or re.match(r"\s*(scratch_store|global_store|buffer_store|ds_write)\S*\s.*\b%s\b" % reg, lines[i])]
-        assert not copies, (name, reg, copies)
+        bad = [lines[i].strip() for i in copies if not any(w < i for w in writes)]
+        assert not bad, (name, reg, bad)

@@ -656,10 +656,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     // coarser claim at the end of a short queue -- and keep single draws.
     constexpr bool DRAW2 = EPI == VIPANT_EPI_QUICKGELU_D8 || EPI == VIPANT_EPI_DQUICKGELU_D8;
     int tk_half = 0;                            // thread 0 (DRAW2): the draw's second position is still to be used
+    // plain launches with >= 8 column tiles per row (qkv: nine) draw pairs too, but single positions for the last 96 of a queue -- 22
+    // tiles per workgroup are few enough for the coarser claim to show at the end (pairs throughout: +12 us against the static
+    // twin; with the taper: 567 -> 551 us, 8 us FASTER than the static twin; bit 29 of VIPANT_GEMM_VARIANT: single draws)
+    int tk_n = DRAW2 ? 2 : ((EPI == VIPANT_EPI_BF16 && !(p.dbg & (1 << 29)) && ntn >= 8) ? 2 : 1);
+    const bool tk_taper = !DRAW2;
     int tk_dry = 0;                             // thread 0: the queue is empty, stop drawing
     int tk_par = 0;                             // the mailbox word this tile's bias round trip reads (it writes the other one)
     int tk_first = 1;                           // the first tile's round trip has nothing to read: its "ticket" is the third static tile
-    if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first), "+v"(tk_half));
+    if (DYN) asm volatile("" : "+v"(tk_dry), "+v"(tk_par), "+v"(tk_first), "+v"(tk_half), "+v"(tk_n));
     auto tk_tile = [&](uint32_t drawn) {
         const int pos = 128 + (int)drawn;
         if (pos < qlen_own) return tickets::tile_of(xq, pos);
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         return NO_TILE;
     };
     if (dyn && tid == 0) {
-        tk_pend = tickets::take_g(tkq, DRAW2 ? 2u : 1u);       // this workgroup's fifth (and sixth) tile; not awaited before the first tile's bias round trip
+        tk_pend = tickets::take_g(tkq, (uint32_t)tk_n);       // this workgroup's fifth (and sixth) tile; not awaited before the first tile's bias round trip
         // the stream's OTHER counter set is at rest (its last user, the stream's previous ticket launch, is complete; the next one
         // starts after this launch): leave it zeroed for that launch -- nobody has to find out who finishes last
         if (blockIdx.x < 8) tickets::put(p.tk_other + blockIdx.x, 0u);
@@ -703,6 +708,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         TileDesc d;
         int tm = tile / ntn, tn = tile % ntn;
         bool valid = tile < ntiles;
+        // ... and the same on the e4m3 kernels' plain static walk (N = 1024 launches of the ViT-L tower: K = 4096 1196 -> 1169 us, K = 3072
+        // 907 -> 884, K = 1024 391 -> 387; bit 28: off).  On the bf16 kernels' static twin it helps where a row has many column tiles
+        // (qkv, nine: 554 -> 540 us) and costs 1-3 % where it has three (N = 768) -- the ticket walk takes it as paired draws, below.
+        if (!GROUPED && ES == 1 && !(p.dbg & (1 << 28)) && valid) {
+            const int q = (tile & 255) >> 5, pos = (tile & 31) + 32 * (tile >> 8);
+            const int w = pos & 31, t = pos >> 5, rounds = ntiles >> 8;       // full rounds only
+            if ((t | 1) < rounds) {
+                const int t2 = tickets::tile_of(q, 64 * (t >> 1) + 2 * w + (t & 1));
+                tm = t2 / ntn; tn = t2 % ntn;
+            }
+        }
         if (GROUPED) {
             const int xcd = (tile & 255) >> 5;
             int sq = (tile & 31) + 32 * (tile >> 8);
@@ -907,7 +923,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
                 if (dyn) {
                     // the ticket drawn one epilogue ago has returned with the loads above: publish it for the next tile's round trip
                     tk_post = (uint32_t)(tk_dry ? NO_TILE : tk_tile(tk_pend + (uint32_t)tk_half));
-                    if (DRAW2) tk_half ^= 1;     // (1: the second position of this draw is next, the coming epilogue draws nothing)
+                    if (tk_n == 2) tk_half ^= 1;     // (1: the second position of this draw is next, the coming epilogue draws nothing)
+                    if (tk_taper && tk_half == 0 && tk_n == 2 && 128 + (int)tk_pend + 96 >= qlen_own) tk_n = 1;
                     tk_par ^= 1;                 // (the store itself goes out at the start of the epilogue, in front of the tile's own stores)
                     // the mailbox word requested behind the previous epilogue (asm load, see there): nk - 1 >= 3 K-tiles of counted
                     // waits have retired it.  It names the tile after `tile_nxt`; a scalar from here.
@@ -996,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
         // epilogue it is issued, and the other waves meet it at the round's barrier.)
         if (dyn && tid == 0) {
             tickets::post_g(mbox + 4 * tk_par, tk_post);
-            if (!tk_dry && !tk_half) tk_pend = tickets::take_g(tkq, DRAW2 ? 2u : 1u);      // not awaited here
+            if (!tk_dry && !tk_half) tk_pend = tickets::take_g(tkq, (uint32_t)tk_n);      // not awaited here
         }
         pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
         // Every wave requests the word posted ONE epilogue ago (the other parity): the index of the tile after the next.  The request
@@ -1372,7 +1389,7 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
     const char* var = getenv("VIPANT_GEMM_VARIANT");       // read per call, as in vipant_gemm_nt
     const int fp8_dbg = var ? atoi(var) : 0;
-    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, fp8_dbg & (4194304 | (1 << 27)), sa, sb, 0, nullptr};
+    GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, aux, lda, ldb, ldc, (int)M, (int)N, (int)K, 1.0f, fp8_dbg & (4194304 | (1 << 27) | (1 << 28)), sa, sb, 0, nullptr};
     p.cq = cq; p.cqs = cq_scale;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
