@@ -482,13 +482,6 @@ int32_t vipant_eot_ln_proj_l2norm_fwd(const float* x, const int64_t* eot, const 
                                       float* out, float* norm, int64_t batch, int64_t L, int64_t D, int64_t E, int32_t normalized,
                                       void* stream);
 
-/* Measurement utility (no reference counterpart): a stand-in for the RCCL all-reduce kernel of one gradient bucket
- * (vipant_amd/parallel.py GradSync.reduce_async; the reference's data_parallel reduces inside cvap/model/cvalp.py:41-61), to measure on
- * ONE GPU what the overlapped reduction costs the step.  nwg workgroups of 256 threads copy `bytes` from src to dst (both 16-byte
- * aligned), each holding its CU (16 KiB of LDS) for at least min_us microseconds.  Only VIPANT_COMM_SHADOW=nwg[:min_us] makes the
- * training path call it (profiles/r5_comm_shadow.md). */
-int32_t vipant_comm_shadow(const void* src, void* dst, size_t bytes, int32_t nwg, float min_us, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,9 @@ def test_full_size_last_block_rows_match_full_block():
     diffs = sorted(((float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)), k) for k in g0), reverse=True)
     print(f"full size, read-out rows vs full last block: feature max rel diff {max_rel(f1, f0):.2e}, loss {l0:.5f} / {l1:.5f}, "
           f"worst gradient rel-L2 diff {diffs[0][0]:.3e} ({diffs[0][1]}), median {diffs[len(diffs) // 2][0]:.3e}")
+    from test_model_gpu import observe
+    observe("full_size_last_block_rows_vs_full_block", loss_full=l0, loss_rows=l1, loss_abs_diff=abs(l1 - l0), feat_max_rel=max_rel(f1, f0),
+            worst_grad_rel_l2=diffs[0][0], median_grad_rel_l2=diffs[len(diffs) // 2][0], batch=B, tokens=S)
     assert max_rel(f1, f0) < 1e-2, max_rel(f1, f0)
     assert abs(l1 - l0) < 1e-3, (l0, l1)
     assert diffs[0][0] < 5e-2, diffs[0]

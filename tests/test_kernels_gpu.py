@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import gen  # noqa: E402  (tests/golden on sys.path via conftest)
+import probe_lib  # noqa: E402  (tools/ on sys.path via conftest; NOT the product library)
 
 
 @pytest.fixture(scope="module")
@@ -400,7 +401,7 @@ def test_mha_bwd_ticket_walk_equals_static_walk(ops, monkeypatch, batch, H, S):
     """Round 5: the persistent attention backward (mha_bwd1s_kernel, one workgroup per CU) draws its third and later problems from the
     stream's ticket counter when batch * heads > 2 x CUs (720, 513 and 516 problems here: long queues, a single drawn problem, four).
     Which workgroup computes a problem must not matter: bit-identical to the static stride (VIPANT_GEMM_VARIANT bit 22), alone and with
-    CUs held by `vipant_comm_shadow` on a second stream, repeatedly (the counters must be back at zero for every launch, also when a
+    CUs held by the probe kernel (tools/probes/comm_shadow.hip) on a second stream, repeatedly (the counters must be back at zero for every launch, also when a
     ticket-walk NT contraction runs in between on the same stream)."""
     D = H * 64
     qkv = rnd(batch * S, 3 * D, seed=11, dtype=torch.bfloat16, scale=1.5)
@@ -418,7 +419,7 @@ def test_mha_bwd_ticket_walk_equals_static_walk(ops, monkeypatch, batch, H, S):
         if held:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ops.call("vipant_comm_shadow", src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
+                probe_lib.comm_shadow(src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
         else:
             ops.gemm_nt(a, w, c, epi=ops.EPI_BF16)
         got = ops.mha_bwd(qkv, out, dout, lse, batch, S, H, False)
@@ -912,7 +913,7 @@ def test_gemm_nt_ticket_walk_equals_static_walk(ops, monkeypatch, M, N, K, epi):
     """Round 5: the persistent NT kernels draw their tiles from per-XCD ticket queues (common.h) so that a workgroup whose CU is held
     by another stream's kernel -- the RCCL all-reduce of a gradient bucket -- costs 1/256 of a launch, not a round.  Which workgroup
     computes a tile must not matter: bit-identical to the static-stride walk (VIPANT_GEMM_VARIANT bit 22), with the chip to itself
-    and with 64 CUs held for 300 us / 24 CUs for 3 ms by `vipant_comm_shadow` on a second stream (late workgroups, some finding their
+    and with 64 CUs held for 300 us / 24 CUs for 3 ms by the probe kernel (tools/probes/comm_shadow.hip) on a second stream (late workgroups, some finding their
     queue empty); every element written each time (the ticket block must be back at zero after every launch)."""
     a = rnd(M, K, seed=61, dtype=torch.bfloat16); b = rnd(N, K, seed=62, dtype=torch.bfloat16, scale=K ** -0.5)
     bias = rnd(N, seed=63)
@@ -940,7 +941,7 @@ def test_gemm_nt_ticket_walk_equals_static_walk(ops, monkeypatch, M, N, K, epi):
         if held:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ops.call("vipant_comm_shadow", src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
+                probe_lib.comm_shadow(src.data_ptr(), dst.data_ptr(), src.numel(), held, us, side.cuda_stream)
         got = run()
         for r_, g_ in zip(ref, got):
             assert torch.equal(r_, g_), (held, us)

@@ -31,6 +31,9 @@ def observe(name, **vals):
         f.write(json.dumps({"test": name, **{k: float(v) for k, v in vals.items()}}) + "\n")
 
 
+TRAJ_CORNERS = {}        # (script, stream, rows) -> (losses of the four steps, calls of the read-out-row kernels)
+
+
 @pytest.fixture(scope="module")
 def M():
     import vipant_amd.module as mod
@@ -724,7 +727,7 @@ def test_e4m3_step_under_the_activation_memory_plans():
 @pytest.mark.parametrize("rows", [True, False], ids=["rows", "fullblock"])
 @pytest.mark.parametrize("stream", ["fp16", "fp32"])
 @pytest.mark.parametrize("tag", ["va", "at"])
-def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
+def test_trainer_trajectory_golden(M, golden, monkeypatch, tag, stream, rows):
     """Four optimisation steps of the product path -- heads, loss head, fused LARS, `adjust_learning_rate` -- against the
     trajectory the REFERENCE's own pieces produced on the same weights and batches (tests/golden/make_golden.py, section viii):
     learning rates exactly, every step's loss, every tunable tensor's update norm, and the final small tensors.  All four corners
@@ -754,7 +757,16 @@ def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
                  weight_decay=1e-6, weight_decay_filter=M.exclude_bias_or_norm, lars_adaptation_filter=M.exclude_bias_or_norm)
     ocfg = NS(epochs=3, warmup_epoch=1, batch_size=b, lr_weight=0.2, lr_bias=0.0048)
     from vipant_amd import ops
-    worst_loss, worst_norm = 0.0, 0.0
+    # which entry points this corner really goes through: the read-out-row kernels of the last block must run iff `rows`
+    # (the budgets below cannot tell a corner that silently took another corner's path)
+    calls = {}
+    real_call = ops.call
+
+    def counting_call(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return real_call(name, *a)
+    monkeypatch.setattr(ops, "call", counting_call)
+    worst_loss, worst_norm, losses, worst_norm_at = 0.0, 0.0, [], ""
     for step in range(4):
         M.adjust_learning_rate(ocfg, opt, range(2), step)
         assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][step][0])) < 1e-9 and abs(opt.param_groups[1]["lr"] - float(g["lrs"][step][1])) < 1e-10
@@ -770,14 +782,22 @@ def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
         loss.backward()
         opt.step()
         worst_loss = max(worst_loss, abs(float(loss) - float(g["losses"][step])))
+        losses.append(float(loss))
         for i, (p, q) in enumerate(zip(params, before)):
             ref = float(g["dnorm"][step][i])
             dn = float((p.detach() - q).norm())
             if ref == 0.0:
                 assert dn == 0.0, (step, named[i][0])
-            else:
-                worst_norm = max(worst_norm, abs(dn / ref - 1))
-    observe(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm)
+            elif abs(dn / ref - 1) > worst_norm:
+                worst_norm, worst_norm_at = abs(dn / ref - 1), f"step {step} {named[i][0]}"
+    n_rows = sum(n for k, n in calls.items() if "rows_ctx" in k or "mha_rows" in k)
+    n_f16 = int(head.encoder.stream_f16)
+    assert (n_rows > 0) == bool(rows), (rows, calls)
+    TRAJ_CORNERS[(tag, stream, rows)] = (tuple(losses), n_rows)
+    observe(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]", worst_loss_err=worst_loss, worst_update_norm_dev=worst_norm,
+            loss_step0=losses[0], loss_step3=losses[3], rows_kernel_calls=n_rows, stream_f16=n_f16,
+            abi_calls=sum(calls.values()))
+    print(f"traj_{tag}[{stream},{'rows' if rows else 'fullblock'}]: losses {losses}; worst update-norm deviation at {worst_norm_at}")
     # b = 8, two blocks: the bf16 towers' loss error at this batch size.  Observed on MI355X in round 5 (profiles/r5_parity_observed.jsonl),
     # worst of four steps over the (stream, last-block) corners: VA 1.6e-3 ... 3.2e-3, AT 1.6e-3 (fp32, rows), 2.2e-3 (fp32, full block),
     # 2.5e-3 / 2.6e-3 (fp16 stream); round 4 had 4.05e-3 with both defaults on (bf16 qk / contexts in the folded last block).  One budget
@@ -792,6 +812,21 @@ def test_trainer_trajectory_golden(M, golden, tag, stream, rows):
             d_hip = p.detach().cpu().double() - init.double()
             if float(d_ref.norm()) > 0:
                 assert float((d_hip - d_ref).norm() / d_ref.norm()) < 0.25, k      # accumulated update direction of a small tensor
+
+
+@pytest.mark.parametrize("tag", ["va", "at"])
+def test_trajectory_corners_are_distinct(tag):
+    """two corners of `test_trainer_trajectory_golden` recorded bit-identical worst errors.  Every corner must
+    have run its own path: the four (stream, last-block) corners of a script give four different loss sequences (bitwise -- a corner
+    that silently fell back to another's path reproduces that one's losses exactly), and the rows corners alone call the read-out-row
+    kernels.  (Equal WORST errors are still possible: the worst step's error is measured against the same reference loss.)"""
+    got = {k: v for k, v in TRAJ_CORNERS.items() if k[0] == tag}
+    if len(got) < 4:
+        pytest.skip("needs the four corners of test_trainer_trajectory_golden in the same session")
+    seqs = [v[0] for v in got.values()]
+    assert len(set(seqs)) == 4, got
+    for (t, stream, rows), (_, n_rows) in got.items():
+        assert (n_rows > 0) == rows, (t, stream, rows, n_rows)
 
 
 def test_frozen_towers_full_depth_golden(M, golden):

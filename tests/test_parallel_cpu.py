@@ -179,3 +179,36 @@ def test_bucket_reduced_inside_backward_reaches_param_grad(tmp_path, overlap):
     (((x @ w1) @ w2).sum() + 2.0 * ((y @ w1) @ w2).sum()).backward()
     assert torch.allclose(s1, w1.grad, atol=1e-4) and torch.allclose(s2, w2.grad, atol=1e-4)
     assert abs(float(lr) - (2 * 64 / 256) * 0.2) < 1e-7
+
+
+def _bare_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vipant_amd import parallel
+        res = {}
+        for overlap in ("block", "step"):
+            sync = parallel.GradSync(overlap=overlap)
+            a, b = torch.full((5,), float(rank + 1)), torch.full((3,), 10.0 * (rank + 1))
+            w = torch.nn.Parameter(torch.zeros(2))
+            w.grad = torch.full((2,), 100.0 * (rank + 1))
+            flat = w.grad.clone()
+            sync.reduce_async(a)                            # bare buckets: reduced IN PLACE, whatever the overlap mode
+            sync.reduce_async(flat, [flat.view_as(w)], [w])
+            sync.reduce_async(b)
+            sync.wait()
+            res[overlap] = (a.clone(), b.clone(), w.grad.clone())
+        if rank == 0:
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bare_buckets_are_reduced_in_place_in_both_overlap_modes(tmp_path):
+    out = str(tmp_path / "bare.pt")
+    mp.spawn(_bare_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    for overlap in ("block", "step"):
+        a, b, g = res[overlap]
+        assert torch.equal(a, torch.full((5,), 3.0)) and torch.equal(b, torch.full((3,), 30.0)) and torch.equal(g, torch.full((2,), 300.0))

@@ -277,6 +277,68 @@ def test_bench_two_ranks_share_the_gpu(script):
 
 
 @pytest.mark.timeout(900)
+def test_bench_gpus_flag_starts_its_own_replicas():
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's 1-GPU command shape with another N): the process starts
+    two replicas itself (vipant_amd/launch.py: child torch.distributed.run, the parent never touches the GPU) and relays rank 0's
+    line.  Over gloo the two replicas share this box's GPU; with the RCCL backend the same command must refuse -- non-zero exit
+    naming the GPU count -- instead of measuring one GPU under the label of two."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+           "--frames", "256", "--mels", "64", "--layers", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=dict(clean, VIPANT_DIST_BACKEND="gloo"), cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["rccl"] == "gloo" and out["config"]["global_batch"] == 32
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=clean, cwd=root)
+        assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert "asked for 2 GPUs but 1 is visible" in res.stderr, res.stderr[-1000:]
+
+
+@pytest.mark.timeout(900)
+def test_train_entry_dp_mode_starts_replicas_and_takes_the_one_process_step(tmp_path):
+    """`num_gpus=2 mode=dp` (run_bimodal_va.sh:23) is the reference's dp step: ONE loader batch of `running.batch_size`, split over
+    the GPUs, loss over the whole batch (cvap/model/cvalp.py:41-61).  train.py starts the two replicas itself; their two steps
+    must be the steps of `num_gpus=1 mode=dp` on the same batch size: same logged losses, same weights in the checkpoint."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = dict(clean, VIPANT_DIST_BACKEND="gloo")
+
+    def run(ngpu, name):
+        ov = (f"+running=bimodal worker=CVALP port=1 num_gpus={ngpu} mode=dp num_proc=2 eval=False verbose=False "
+              f"alias_root={tmp_path} model_name={name} +model/image=vit_val +model/audio=vit_val +model/text=dummy +model/loss=ce "
+              "+optimizer=standard +running/audio=default model.audio.pre_encoder.in_channels=3 "
+              "model.audio.pre_encoder.stride=[16,24] optimizer.warmup=False running.audio.norms=[-4.93839311,5.75751113] "
+              "model.image.encoder.layers=1 running.audio.max_len=256 running.audio.num_mel_bins=64 running.batch_size=8 "
+              "running.synthetic_steps=2 running.epochs=1 running.peep_rate=1 running.frame_emb=synthetic running.save_rate=2").split()
+        res = subprocess.run([sys.executable, os.path.join(root, "train.py")] + ov, capture_output=True, text=True, timeout=800,
+                             env=env, cwd=root)
+        assert res.returncode == 0, res.stderr[-3000:]
+        log = (tmp_path / name / "train_0.out").read_text()
+        losses = [float(m.group(1)) for m in re.finditer(r" loss ([0-9.]+) ", log)]
+        ck = torch.load(tmp_path / name / "00000002.pth", weights_only=False)
+        return log, losses, ck
+
+    log1, loss1, ck1 = run(1, "one")
+    log2, loss2, ck2 = run(2, "two")
+    assert "World size: 1; rank: 0" in log1 and "World size: 2; rank: 0" in log2 and (tmp_path / "two" / "train_1.out").exists()
+    assert "per-process batch 4 x 2 replica(s) = global batch 8" in log2 and "global batch 8" in log1
+    assert len(loss1) == 2 and loss1 == loss2, (loss1, loss2)                 # logged with three decimals
+    for k, v in ck1["model"][1].items():
+        err = float((v.float() - ck2["model"][1][k].float()).abs().max())
+        assert err <= 1e-6 + 2e-4 * float(v.float().abs().max()), (k, err)
+
+
+@pytest.mark.timeout(900)
 def test_train_entry_two_ranks_share_the_gpu(tmp_path):
     """`train.py` with the VA launch script's overrides under torch.distributed.run, two ranks on this box's one GPU (gloo):
     group set-up from the environment, per-rank synthetic batches, the replica exchange steps inside Monitor.epoch, rank-0 logging

@@ -1,6 +1,6 @@
 """What does sharing the chip with the gradient all-reduce cost the step?  (profiles/r5_comm_shadow.md)
 
-One process, one GPU, the headline VA step (bench.py's workload).  A stand-in kernel (`vipant_comm_shadow`: N workgroups x 256 threads
+One process, one GPU, the headline VA step (bench.py's workload).  A stand-in kernel (`probe_comm_shadow`, tools/probes/comm_shadow.hip: N workgroups x 256 threads
 copying a block's 28 MB bucket, each holding its CU for at least T us) is launched on the side stream wherever
 GradSync.reduce_async would start the RCCL all-reduce.  Settings are interleaved in one process (boxes differ by +-2 %):
 
@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    os.environ["VIPANT_COMM_SHADOW"] = "1:0"          # so that the Monitor builds its GradSync; switched per segment below
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import probe_lib
     from vipant_amd import _ffi
     from vipant_amd.config import compose
     from vipant_amd.monitor import VAMonitor
@@ -49,6 +50,7 @@ def main():
     mon = VAMonitor(cfg, (lambda *_: None), dev)
     mon.total_loss = mon.total_step = mon.total_inst = 0
     mon.start_time = time.time()
+    sync = probe_lib.install(mon, probe_lib.ShadowGradSync())      # the stand-in takes GradSync's place; switched per segment below
     g = torch.Generator().manual_seed(1213)
     images = torch.randn(b, 3, 224, 224, generator=g).to(dev)
     audios = torch.randn(b, 1, T, Fq, generator=g).to(dev)
@@ -62,8 +64,8 @@ def main():
 
     def timed(walk, overlap, shadow):
         os.environ["VIPANT_GEMM_VARIANT"] = "4194304" if walk == "static" else "0"
-        os.environ["VIPANT_COMM_SHADOW"] = shadow
-        mon.grad_sync.overlap = overlap
+        nwg, _, us = shadow.partition(":")
+        sync.nwg, sync.min_us, sync.overlap = int(nwg), float(us or 0.0), overlap
         run(2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

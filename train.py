@@ -3,20 +3,23 @@
     python train.py +running=bimodal worker=CVALP mode=dp +model/image=vit_val +model/audio=vit_val \
         +model/text=dummy +model/loss=ce +optimizer=standard +running/audio=default key=value ...
 
-`mode=dp`  : one process, one MI355X (the reference's dp mode would replicate over `num_gpus` with
-             torch.nn.parallel.data_parallel; here data parallelism is always one process per GPU).
-`mode=ddp` : one replica per GPU.  Launch with torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env);
-             backend "nccl" is RCCL over xGMI on ROCm.
+`mode=dp`  : the reference's dp step (train.py:68-71, cvap/model/cvalp.py:41-61): ONE loader yields `running.batch_size` samples,
+             the towers run on `num_gpus` GPUs with the batch split in contiguous chunks, the loss scores the whole batch.  Here
+             data parallelism is one process per GPU, so `num_gpus=N mode=dp` starts N replicas by itself (a child
+             `torch.distributed.run`, vipant_amd/launch.py): each takes its `batch_size / N` chunk of the loader's batch, the
+             features are all-gathered (global negatives), the gradients all-reduced over RCCL.  `num_gpus=1`: one process.
+`mode=ddp` : one replica per GPU, `running.batch_size` PER replica.  Launch with torchrun (RANK / LOCAL_RANK / WORLD_SIZE /
+             MASTER_* in the env); backend "nccl" is RCCL over xGMI on ROCm.
 """
 import os
 import sys
 
-import torch
-import torch.distributed as dist
-
-from vipant_amd import monitor as monitors
+from vipant_amd import launch
 from vipant_amd.config import compose, to_yaml
-from vipant_amd.util import seed_all_rng, setup_logger
+
+# torch, the HIP library and the trainer are imported by train() AFTER the decision whether this process is a replica or the parent
+# that starts the replicas: that parent must never touch the GPU
+torch = dist = monitors = seed_all_rng = setup_logger = None
 
 
 def main(cfg, rank, device, manager):
@@ -33,8 +36,35 @@ def main(cfg, rank, device, manager):
     monitor_cls(cfg, logger.info, device).learn()
 
 
+def dp_chunk(cfg, world):
+    """`mode=dp` under `world` replicas: `running.batch_size` is the loader's (global) batch, as in the reference; a replica's towers
+    take a contiguous chunk of it (data_parallel's scatter, cvalp.py:41-56) and the loss scores all of it."""
+    B = int(cfg.running.batch_size)
+    if B % world:
+        raise ValueError(f"mode=dp: running.batch_size={B} does not split evenly over num_gpus={world} replicas")
+    cfg.running.batch_size = B // world
+    cfg.optimizer.batch_size = B // world        # the LARS schedule multiplies by the replica count again (module/lars.py)
+    cfg.running.dp_chunk = True                  # the synthetic loader: chunk `rank` of ONE global batch, not a batch per rank
+    cfg.running.negatives = "global"
+
+
 def train(argv=None):
-    cfg = compose(sys.argv[1:] if argv is None else argv)
+    argv = sys.argv[1:] if argv is None else list(argv)
+    cfg = compose(argv)
+    ngpu = int(cfg.get("num_gpus", 1) or 1)
+    if cfg.mode == "dp" and ngpu > 1 and not launch.under_launcher():
+        # the reference's dp launch (run_bimodal_va.sh:23 `num_gpus=$ngpu mode=dp`): start the replicas, relay their exit code
+        rc = launch.replicas(os.path.abspath(__file__), argv, ngpu)
+        if rc:
+            sys.exit(rc)
+        return
+    global torch, dist, monitors, seed_all_rng, setup_logger
+    import torch
+    import torch.distributed as dist
+    from vipant_amd import monitor as monitors
+    from vipant_amd.util import seed_all_rng, setup_logger
+    if cfg.mode == "dp" and launch.under_launcher() and int(os.environ["WORLD_SIZE"]) > 1:
+        dp_chunk(cfg, int(os.environ["WORLD_SIZE"]))
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1 or cfg.mode == "ddp" and "RANK" in os.environ:
         backend = os.environ.get("VIPANT_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for shared-GPU tests
         local_rank, ndev = int(os.environ.get("LOCAL_RANK", 0)), max(torch.cuda.device_count(), 1)

@@ -117,7 +117,6 @@ PROTOTYPES = {
     "vipant_eot_ln_proj_l2norm_fwd": (_i32, [_p] * 12 + [_i64] * 4 + [_i32, _p]),
     "vipant_lars_workspace_bytes": (_sz, [_i64]),
     "vipant_lars_step": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _p, _sz, _p]),
-    "vipant_comm_shadow": (_i32, [_p, _p, _sz, _i32, _f32, _p]),
 }
 
 

@@ -154,6 +154,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+PROBES_DIR = os.path.join(HERE, "..", "tools", "probes")
+PROBES_LIB = os.path.join(PROBES_DIR, "libvipant_probes.so")
+PROBE_SOURCES = ("comm_shadow.hip",)
+
+
+def build_probes(force: bool = False, verbose: bool = True) -> str:
+    """tools/probes/libvipant_probes.so: measurement probes used by tools/ and by the ticket-walk tests (a kernel that holds CUs on a
+    second stream).  Deliberately a separate library: nothing of it is linked into, or reachable from, libvipant_hip.so."""
+    srcs = [os.path.join(PROBES_DIR, n) for n in PROBE_SOURCES]
+    if force or _older(PROBES_LIB, srcs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", PROBES_LIB, *srcs]
+        if verbose:
+            print("[vipant_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return PROBES_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_probes(force="--force" in sys.argv)
     print(LIB)

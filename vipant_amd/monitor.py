@@ -30,12 +30,18 @@ SOT, EOT = 49406, 49407
 class SyntheticLoader:
     """Batches with the tensor contract of the reference collators (cvap/data/audioset_clf.py:122-152,
     cvap/monitor/cvalp.py:136-154): (images, audios [b, T, F], text [b, L] i64, labels, names).  Seeded per rank and
-    per step, reproducible."""
+    per step, reproducible.  `running.dp_chunk` (set by train.py for `mode=dp` under N replicas): the loader
+    stands for the reference's ONE loader whose batch data_parallel scatters -- every replica draws the same global batch of
+    N x batch_size samples and keeps its contiguous chunk."""
 
     def __init__(self, cfg, steps, with_text, device_rank=0):
         self.cfg, self.steps, self.with_text, self.rank = cfg, int(steps), with_text, device_rank
         rcfg = cfg.running
         self.b = int(rcfg.batch_size)
+        self.chunk = None
+        if rcfg.get("dp_chunk", False) and parallel.world_size() > 1:
+            self.chunk = (parallel.rank(), self.b)
+            self.b, self.rank = self.b * parallel.world_size(), 0
         self.T, self.F = int(rcfg.max_audio_len), int(rcfg.num_mel_bins)
         self.precomputed = bool(rcfg.get("precomputed_image", False)) or rcfg.get("frame_emb", None) is not None
         self.res = int(cfg.running.resolution) if not isinstance(cfg.running.resolution, (list, tuple)) else 224
@@ -64,6 +70,9 @@ class SyntheticLoader:
                 text = torch.zeros(self.b, 1, dtype=torch.int64)
             labels = torch.zeros(self.b, dtype=torch.int64)
             names = [f"synthetic-{self.rank}-{step}-{i}" for i in range(self.b)]
+            if self.chunk is not None:
+                sl = slice(self.chunk[0] * self.chunk[1], (self.chunk[0] + 1) * self.chunk[1])
+                images, audios, text, labels, names = images[sl], audios[sl], text[sl], labels[sl], names[sl]
             yield images, audios, text, labels, names
 
 
@@ -80,7 +89,7 @@ class Monitor(object):
         tunable_params = model.build(negatives=negatives)
         self.model = model
         self.grad_sync = None
-        if parallel.active() or parallel.shadow() is not None:
+        if parallel.active():
             # `running.comm_overlap`: block (default: each block's bucket is reduced while the blocks below run their backward) | step
             self.grad_sync = parallel.GradSync(overlap=str(cfg.running.get("comm_overlap", "block")))
             for head in (model.audio_head, model.image_head, model.text_head):

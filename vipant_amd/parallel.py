@@ -15,10 +15,6 @@ the CPU tests).  The path shards by samples; there are exactly two exchange step
      overlapping the backward of the blocks below; "step" -- all of a step's block buckets as ONE all-reduce after the backward
      (nothing shares the chip with the backward, the reduction is exposed).  DESIGN.md section 6 has the numbers behind the default.
 
-VIPANT_COMM_SHADOW=nwg[:min_us] (one process, no group): every bucket hand-over launches `vipant_comm_shadow` on the side stream
-instead of a collective -- nwg workgroups copying the bucket, each holding its CU for at least min_us -- so that the cost of sharing
-the chip with the reduction's kernel can be measured on one GPU (tools/comm_shadow.py, profiles/r5_comm_shadow.md).
-
 Device-agnostic on purpose: the same code runs under gloo on CPU tensors in tests/test_parallel_cpu.py.
 """
 from __future__ import annotations
@@ -40,15 +36,6 @@ def world_size() -> int:
 
 def rank() -> int:
     return dist.get_rank() if is_dist() else 0
-
-
-def shadow():
-    """(workgroups, microseconds) of the single-GPU stand-in for the bucket all-reduce, or None (VIPANT_COMM_SHADOW=nwg[:min_us])."""
-    spec = os.environ.get("VIPANT_COMM_SHADOW", "")
-    if not spec or spec == "0":
-        return None
-    nwg, _, us = spec.partition(":")
-    return int(nwg), float(us or 0.0)
 
 
 def active() -> bool:
@@ -103,7 +90,6 @@ class GradSync:
         self.pairs: List = []
         self.deferred: List = []            # overlap == "step": (flat, views, params) held back until wait()
         self.stream: Optional[torch.cuda.Stream] = None
-        self._shadow_dst: Optional[torch.Tensor] = None
 
     def _comm_stream(self, device):
         if self.stream is None:
@@ -115,27 +101,12 @@ class GradSync:
         `flat` that are the gradients of `params`: autograd usually CLONES a gradient it is handed while other
         references to it exist, so after the reduction `wait()` copies the reduced slices over whatever tensor ended
         up in `param.grad`."""
-        if self.overlap == "step" and (active() or shadow() is not None):
+        if self.overlap == "step" and active():
             self.deferred.append((flat, views, params))
             return
         self._start(flat, views, params)
 
     def _start(self, flat: torch.Tensor, views=None, params=None):
-        sh = shadow()
-        if sh is not None and not active():
-            if flat.is_cuda:                       # the collective's stand-in: same stream hand-off, a copy kernel that holds CUs
-                from . import _ffi
-                comm = self._comm_stream(flat.device)
-                comm.wait_stream(torch.cuda.current_stream(flat.device))
-                if self._shadow_dst is None or self._shadow_dst.numel() < flat.numel():
-                    self._shadow_dst = torch.empty_like(flat)
-                nbytes = flat.numel() * flat.element_size() // 16 * 16
-                with torch.cuda.stream(comm):
-                    # min_us is quoted for one block's bucket of the ViT-B tower (28.4 MB); other sizes hold in proportion
-                    _ffi.call("vipant_comm_shadow", flat.data_ptr(), self._shadow_dst.data_ptr(), nbytes, sh[0],
-                              sh[1] * max(nbytes / 28.4e6, 0.05), comm.cuda_stream)
-                flat.record_stream(comm)
-            return
         if not active():
             return
         if views is not None:
@@ -172,6 +143,7 @@ class GradSync:
         A parameter can own several slices -- a siamese shared encoder runs the stack twice over the same weights, once per
         tower, and each run hands over its own bucket -- so the slices of one parameter are summed; the first one is
         installed as `.grad` by reference (no 352 MB copy-back per step), the rest are added to it."""
+        back = []
         if self.deferred:                    # overlap == "step": one flat buffer, one collective; the views move into it
             held, self.deferred = self.deferred, []
             if len(held) == 1:
@@ -180,6 +152,8 @@ class GradSync:
                 flat = torch.cat([f for f, _, _ in held])
                 views, params, off = [], [], 0
                 for f, vs, ps in held:
+                    if not vs:          # a bare bucket: reduce_async's in-place contract -- the reduced slice goes back into it
+                        back.append((f, flat[off:off + f.numel()]))
                     for v, p in zip(vs or [], ps or []):
                         o = off + v.storage_offset() - f.storage_offset()
                         views.append(flat[o:o + v.numel()].view(v.shape))
@@ -190,6 +164,8 @@ class GradSync:
             h.wait()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        for f, red in back:
+            f.copy_(red.view_as(f))
         first = set()
         for p, v in self.pairs:
             if p.grad is None:
