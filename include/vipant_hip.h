@@ -216,6 +216,24 @@ int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t
  * point at the first of those columns. */
 int32_t vipant_quant_e4m3_mx_cols(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
                                   int64_t kt_row, int64_t kb0, void* stream);
+/* Block-UNIFORM scales (round 6): the same bytes-plus-scales format with every scale shared by an aligned block of 32 rows x 32
+ * columns (the byte is stored for each of the 32 rows, in the layout above, so the NT contractions read the matrix unchanged).  One
+ * scale per (32 tokens, 32 columns) is also one scale per 32 k of a COLUMN, which is what v_mfma_scale_f32_16x16x128_f8f6f4 needs when k
+ * runs along the token axis: the operand format of vipant_gemm_tn_e4m3.  vipant_quant_e4m3_mx32: from bf16 (e = the smallest exponent
+ * with max|block| / 2^e <= 448 over the 32 x 32 block).  vipant_mx_uniform32: IN PLACE on an e4m3 matrix with row-wise block scales (what
+ * the producers emit): the block's scale becomes the largest of its rows' scales, the other rows' bytes are divided by the power of
+ * two -- exact unless a value falls below e4m3's normal range.  No reference counterpart (BASELINE.json configs[4]). */
+int32_t vipant_quant_e4m3_mx32(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                               void* stream);
+int32_t vipant_mx_uniform32(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, void* stream);
+/* Weight-gradient contraction on e4m3 operands (BASELINE.json configs[4]; the autograd of nn.Linear weight, cvap/module/val.py:500-506,
+ * as vipant_gemm_tn): C[P, Q] fp32 (+)= dequant(A, sa)^T dequant(B, sb), reduction over the token dimension M.  A [M, P], B [M, Q]:
+ * token-major e4m3 bytes with block-uniform scales (above); lda / ldb = the row length of the quantised matrices (what their scale
+ * layouts were written with), P and Q multiples of 128.  fp32 accumulation, deterministic split over M through `workspace`. */
+size_t vipant_gemm_tn_e4m3_workspace_bytes(int64_t M, int64_t P, int64_t Q);
+int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb, float* C,
+                            int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream);
 /* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result -- vipant_quant_e4m3_mx of `out`
  * [M, D] resp. `dqkv` [M, 3 D], bit for bit -- for the contraction that follows (out_proj; in_proj^T).  No reference counterpart
  * (BASELINE.json configs[4]).  The streamed single-pass backward (224 < S <= 320, no mask) emits the dK | dV columns from its own

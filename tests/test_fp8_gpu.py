@@ -80,6 +80,102 @@ def test_block_quantiser_matches_the_stated_format(ops, M, K):
     assert float(rel.max()) <= 2 ** -4 + 1e-6                                              # half an ulp of the BLOCK maximum
 
 
+def emulate_quant_mx32(x_bf16):
+    """block-uniform format (round 6): one exponent per aligned block of 32 rows x 32 columns; (q float8 [M, K], scale bytes [M, K / 32])."""
+    M, K = x_bf16.shape
+    Mp = (M + 31) // 32 * 32
+    x = torch.zeros(Mp, K, dtype=torch.float32, device=x_bf16.device)
+    x[:M] = x_bf16.float()
+    blk = x.view(Mp // 32, 32, K // 32, 32)
+    amax = blk.abs().amax(dim=(1, 3))
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))) - 8
+    e = torch.where(amax * torch.exp2(-e) > 448, e + 1, e)
+    e = torch.where(amax > 0, e, torch.zeros_like(e)).clamp(-127, 127)
+    q = (blk * torch.exp2(-e)[:, None, :, None]).to(torch.float8_e4m3fn).view(Mp, K)[:M]
+    s = (e + 127).to(torch.uint8)[:, None, :].expand(Mp // 32, 32, K // 32).reshape(Mp, K // 32)[:M]
+    return q, s
+
+
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096), (129, 3072), (128, 128), (248, 2304)])
+def test_block_uniform_quantiser_matches_the_stated_format(ops, M, K):
+    """vipant_quant_e4m3_mx32 bit for bit against torch's float8_e4m3fn rounding: bytes, and every row's scale byte at its place in
+    the MX layout (the block's scale, 32 times)."""
+    rows = torch.exp2(torch.randint(-12, 12, (M, 1), device=DEV).float())
+    x = (rnd(M, K, seed=M + K) * rows).to(torch.bfloat16)
+    x[:, 40:70] *= 64.0
+    x[0].zero_()
+    x[1, 3] = 448.0 * 2 ** 5
+    if M > 40:
+        x[32:64, 64:96].zero_()                                                            # an all-zero block
+    q, s = ops.quant_e4m3_mx32(x)
+    q_ref, s_ref = emulate_quant_mx32(x)
+    assert torch.equal(mx_scales(ops, s, M, K), s_ref)
+    assert torch.equal(q, q_ref.contiguous().view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (129, 3072), (248, 2304)])
+def test_uniform_pass_is_an_exact_rescaling(ops, M, K):
+    """vipant_mx_uniform32 in place on the row-wise format: scales become the block maxima of the row-wise scales; the dequantised
+    matrix is unchanged except where a value falls below e4m3's normal range under the block's scale (then within half a subnormal step:
+    2^-10 of the block scale's unit); rows that already carried the block's scale keep their bytes."""
+    rows = torch.exp2(torch.randint(-6, 6, (M, 1), device=DEV).float())
+    x = (rnd(M, K, seed=3 * M + K) * rows).to(torch.bfloat16)
+    x[0].zero_()
+    q, s = ops.quant_e4m3_mx(x)
+    before = dequant_mx(ops, q, s)
+    s_rows = mx_scales(ops, s, M, K).clone()
+    q0 = q.clone()
+    ops.mx_uniform32(q, s)
+    s_blk = mx_scales(ops, s, M, K)
+    Mp = (M + 31) // 32 * 32
+    pad = torch.zeros(Mp, K // 32, dtype=torch.uint8, device=DEV); pad[:M] = s_rows
+    want = pad.view(Mp // 32, 32, K // 32).amax(dim=1)[:, None, :].expand(Mp // 32, 32, K // 32).reshape(Mp, K // 32)[:M]
+    assert torch.equal(s_blk, want)
+    same = (s_rows == s_blk)[:, :, None].expand(M, K // 32, 32).reshape(M, K)
+    assert torch.equal(q[same], q0[same])
+    after = dequant_mx(ops, q, s)
+    unit = torch.exp2(s_blk.float() - 127)[:, :, None].expand(M, K // 32, 32).reshape(M, K)
+    assert float(((after - before).abs() / unit).max()) <= 2 ** -10 + 1e-9
+    normal = before.abs() >= unit * 2 ** -6
+    assert torch.equal(after[normal], before[normal])
+
+
+@pytest.mark.parametrize("M,P,Q", [(128, 128, 128), (256, 256, 256), (1000, 768, 768), (4100, 2304, 768), (2528, 1024, 4096), (248, 768, 3072),
+                                   (40448, 1024, 1024)])
+def test_e4m3_weight_gradient_contraction_is_exact_on_its_operands(ops, M, P, Q):
+    """vipant_gemm_tn_e4m3: C = dequant(A)^T dequant(B) with k along the TOKEN axis on block-uniform operands -- against an fp64 product
+    of the same dequantised operands, with and without accumulation, and its distance to the unquantised product reported.  The budget
+    is the instruction's own: v_mfma_scale_f32_16x16x128_f8f6f4 sums its 128 products with fewer bits than fp32 (observed on MI355X: every
+    element a few 1e-4 of its own magnitude SHORT of the exact sum -- always towards zero, what a truncating adder tree gives -- 2e-5 ...
+    1e-4 of the result's largest element; tools/tn8_debug.py), three orders of magnitude below the operands' e4m3 rounding."""
+    ra = torch.exp2(torch.randint(-6, 7, (M, 1), device=DEV).float())
+    a = (rnd(M, P, seed=11) * ra).to(torch.bfloat16)
+    b = (rnd(M, Q, seed=12) * ra.flip(0)).to(torch.bfloat16)
+    a[:, 64:96] *= 32.0
+    qa, sa = ops.quant_e4m3_mx32(a)
+    qb, sb = ops.quant_e4m3_mx32(b)
+    c = torch.full((P, Q), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn_e4m3(qa, sa, qb, sb, c)
+    ref = dequant_mx(ops, qa, sa).double().t() @ dequant_mx(ops, qb, sb).double()
+    scale = ref.abs().amax()
+    err = float((c.double() - ref).abs().max() / scale)
+    assert err < 4e-4, err
+    c2 = c.clone()
+    ops.gemm_tn_e4m3(qa, sa, qb, sb, c2, accumulate=True)
+    assert float((c2.double() - 2 * c.double()).abs().max() / scale) < 1e-6            # the accumulate path itself is fp32-exact
+    full = a.double().t() @ b.double()
+    dist = float((c.double() - full).norm() / full.norm())
+    print(f"e4m3 TN [{M}, {P}] x [{M}, {Q}]: {err:.2e} of the dequantised product's scale; {dist:.3e} rel-L2 from the unquantised product")
+    assert dist < 6e-2, dist
+    # the same operands made block-uniform by the in-place pass from the row-wise format
+    qa2, sa2 = ops.quant_e4m3_mx(a); ops.mx_uniform32(qa2, sa2)
+    qb2, sb2 = ops.quant_e4m3_mx(b); ops.mx_uniform32(qb2, sb2)
+    c3 = torch.empty_like(c)
+    ops.gemm_tn_e4m3(qa2, sa2, qb2, sb2, c3)
+    ref3 = dequant_mx(ops, qa2, sa2).double().t() @ dequant_mx(ops, qb2, sb2).double()
+    assert float((c3.double() - ref3).abs().max() / scale) < 4e-4
+
+
 @pytest.mark.parametrize("M,K", [(5, 256), (300, 1024), (1031, 768), (64, 4096), (33, 5120), (17, 8192)])
 def test_quantiser_matches_the_stated_format(ops, M, K):
     rows = torch.exp2(torch.randint(-12, 12, (M, 1), device=DEV).float())                 # row magnitudes over 24 octaves

@@ -441,6 +441,115 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __rest
     }
 }
 
+
+// Block-uniform MX scales (the operand format of vipant_gemm_tn_e4m3): one power-of-two scale per aligned block of 32 ROWS x 32 columns,
+// stored -- redundantly, 32 times -- in the MX layout of the row-wise format, so that the NT contractions read such a matrix as they
+// read any other (a block scale is a valid scale for every one of its rows) and the weight-gradient contraction, whose k runs along
+// the rows, finds one scale per 32 k of a column.  A workgroup takes 32 rows x 256 columns: thread t holds the 16-byte chunk t & 31 of
+// rows (t >> 5) + 8 i; the block maximum goes through DPP (the four chunks of a 32-column block are four lanes) and an 8 x 8 LDS table.
+__global__ __launch_bounds__(256) void quant_e4m3_mx32_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                              int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K, int nct) {
+    __shared__ uint32_t tab[8][8];
+    const int t = threadIdx.x, ch = t & 31, rg = t >> 5;
+    const int64_t nrt = (M + 31) / 32;
+    for (int64_t tile = blockIdx.x; tile < nrt * nct; tile += gridDim.x) {
+        const int64_t r0 = (tile / nct) * 32;
+        const int col = (int)(tile % nct) * 256 + ch * 8;
+        const bool col_ok = col < K;                          // whole 32-column blocks are in or out (K % 32 == 0)
+        u32x4 w[4];
+        uint32_t mx = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = r0 + rg + 8 * i;
+            w[i] = (col_ok && row < M) ? *(const u32x4*)(x + row * ldx + col) : u32x4{0u, 0u, 0u, 0u};
+            mx = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(mx, w[i][0]), w[i][1]), w[i][2]), w[i][3]);
+        }
+        uint32_t m1 = max(mx & 0xFFFFu, mx >> 16);
+        m1 = mx_lane_max_u<4>(m1);
+        if ((ch & 3) == 0) tab[rg][ch >> 2] = m1;
+        __syncthreads();
+        uint32_t bm = 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bm = max(bm, tab[r][ch >> 2]);
+        float sc;
+        const uint32_t byte = mx_scale_of_max(bm, &sc);
+        if (col_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = r0 + rg + 8 * i;
+                if (row < M) *(int2*)(q + row * ldq + col) = int2{mx_pack4_bf16(w[i][0], w[i][1], sc), mx_pack4_bf16(w[i][2], w[i][3], sc)};
+            }
+        }
+        // the 32 rows' scale bytes of the tile's 8 column blocks: thread t writes (row t >> 3, block t & 7)
+        {
+            uint32_t bm2 = 0u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bm2 = max(bm2, tab[r][t & 7]);
+            float unused;
+            const uint32_t b2 = mx_scale_of_max(bm2, &unused);
+            const int64_t row = r0 + (t >> 3);
+            const int kb = (int)(tile % nct) * 8 + (t & 7);
+            if (row < M && kb * 32 < K) scale[mx_scale_offset(row, kb, K >> 7)] = (uint8_t)b2;
+        }
+        (void)byte;
+        __syncthreads();
+    }
+}
+
+// In place: an e4m3 matrix with row-wise MX scales (what the producers emit) -> block-uniform scales.  The block's scale is the
+// largest of its 32 rows' scales; a row whose scale was smaller by d has its bytes divided by 2^d -- exact (a power of two) unless
+// the result falls below e4m3's normal range (values 2^15 below the block's largest, rounded to the subnormal grid).  Rows that
+// already carry the block's scale are not rewritten.
+__global__ __launch_bounds__(256) void mx_uniform32_kernel(uint8_t* __restrict__ q, int64_t ldq, uint8_t* __restrict__ scale, int64_t M,
+                                                           int K, int nct) {
+    __shared__ uint32_t tab[8][8];
+    const int t = threadIdx.x, ch = t & 31, rg = t >> 5;
+    const int64_t nrt = (M + 31) / 32;
+    const int ktr = K >> 7;
+    for (int64_t tile = blockIdx.x; tile < nrt * nct; tile += gridDim.x) {
+        const int64_t r0 = (tile / nct) * 32;
+        const int col = (int)(tile % nct) * 256 + ch * 8;
+        const int kb = col >> 5;
+        const bool col_ok = col < K;
+        uint32_t sb[4], smax = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = r0 + rg + 8 * i;
+            sb[i] = (col_ok && row < M) ? scale[mx_scale_offset(row, kb, ktr)] : 0u;
+            smax = max(smax, sb[i]);
+        }
+        if ((ch & 3) == 0) tab[rg][ch >> 2] = smax;
+        __syncthreads();
+        uint32_t S = 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) S = max(S, tab[r][ch >> 2]);
+        if (col_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = r0 + rg + 8 * i;
+                if (row >= M || sb[i] == S) continue;
+                const uint32_t d = S - sb[i];
+                const float f = d >= 64u ? 0.f : __uint_as_float((127u - d) << 23);       // 2^-d
+                uint8_t* pq = q + row * ldq + col;
+                const int2 v = *(const int2*)pq;
+                int o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int src = h ? v.y : v.x;
+                    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(src, false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8(src, true);
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0] * f, lo[1] * f, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(hi2[0] * f, hi2[1] * f, w, true);
+                    o[h] = w;
+                }
+                *(int2*)pq = int2{o[0], o[1]};
+                if ((ch & 3) == 0) scale[mx_scale_offset(row, kb, ktr)] = (uint8_t)S;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" size_t vipant_mx_scale_bytes(int64_t M, int64_t K) { return K > 0 && K % 128 == 0 && M > 0 ? mx_scale_bytes(M, K) : 0; }
@@ -464,6 +573,28 @@ extern "C" int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t*
                                         void* stream) {
     VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
     return vipant_quant_e4m3_mx_cols(x, ldx, q, ldq, scale, M, K, K / 128, 0, stream);
+}
+
+extern "C" int32_t vipant_quant_e4m3_mx32(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                          void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx32: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+    VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr,
+                   VIPANT_EALIGN, "quant_e4m3_mx32: misaligned rows");
+    const int64_t nct = ceil_div(K, 256), tiles = ceil_div(M, 32) * nct;
+    hipLaunchKernelGGL(quant_e4m3_mx32_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K, (int)nct);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_mx_uniform32(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "mx_uniform32: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+    VIPANT_REQUIRE(ldq >= K && ldq % 8 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr, VIPANT_EALIGN, "mx_uniform32: misaligned rows");
+    const int64_t nct = ceil_div(K, 256), tiles = ceil_div(M, 32) * nct;
+    hipLaunchKernelGGL(mx_uniform32_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream, q, ldq, scale,
+                       M, (int)K, (int)nct);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
 }
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,

@@ -415,6 +415,249 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pp_pair_kernel(GemmTNPair pr) 
     tn_pp_body(first ? pr.a : pr.b, first ? (int)blockIdx.x : (int)blockIdx.x - pr.blocks_a, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// e4m3 operands (BASELINE.json configs[4]): the same ping-pong stream on v_mfma_scale_f32_16x16x128_f8f6f4 with the TOKEN axis as K.
+// Both operands are token-major e4m3 matrices exactly as the NT contractions read them ([M, P] and [M, Q], one byte per element)
+// whose MX scales are UNIFORM over aligned blocks of 32 tokens x 32 columns (vipant_quant_e4m3_mx32 / vipant_mx_uniform32, or a
+// producer that emits them that way): one scale per (32 tokens, 32 columns) is then also one scale per 32 k of a column, which is
+// what the instruction's block-scale operand needs when k runs along the tokens -- no transposed copy, no second quantisation.
+//   * K-tile = 128 tokens = ONE MFMA k-step.  LDS images as in the bf16 kernel, byte for byte: A stages [128 m][128 p] = 16 KiB per
+//     group and stage, B slots [128 m][256 q] = 32 KiB, filled by LDS-DMA as the rows lie in HBM (16-byte chunks XOR-swizzled by
+//     row: f_A(m) = m[2:1] | m[4] << 2 on 128-byte rows, f_B(m) = m[2:0] | m[4] << 3 on 256-byte rows).
+//   * fragments by ds_read_b64_tr_b8 (tools/probes/tr8_probe.hip: per 16 lanes an 8-row x 16-column byte block, lane 2 q + h gives
+//     the address of row q, columns 8 h .. 8 h + 7, lane i receives column i, rows 0-7 in bytes 0-7).  The instruction wants, in
+//     lane (r, qd), k = 16 qd .. + 15 in dwords 0-3 and k = 64 + 16 qd .. in dwords 4-7 of column r: four transposed reads per
+//     16-column fragment; with the swizzles above the 16 row segments of a 32-lane half fall on 16 distinct 16-byte bank groups.
+//   * scales: lane (r, qd) supplies the scale of (its column's 32-column block, token block 4 kt + qd).  In the MX layout (common.h)
+//     the bytes of one 128-token group and one 128-column group are 32 contiguous bytes [kb & 3][row tile 0-7]; rows 32 qd of the
+//     group are row tile 2 qd: one 32-byte (A) / 16-byte (B) load per wave and K-tile, a K-tile ahead, in front of that K-tile's DMA
+//     pieces (older than all of them: the counted waits cover it).  Token blocks at or beyond M carry 2^0 (their bytes read as zero).
+// The two barrier intervals of a K-tile take the wave's row tiles 0-3 and 4-7 (16 MFMAs of 32 cycles each); the B fragments are
+// read in the first interval and kept.  DMA piece counts, lag and waits are the bf16 kernel's.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int V> struct Int { static constexpr int value = V; };
+
+struct GemmTN8 {
+    const uint8_t* A; const uint8_t* B; const uint8_t* sa; const uint8_t* sb; float* out;
+    int64_t lda, ldb, ldo;       // lda / ldb: bytes per token row (= columns of the quantised matrices: their scale layouts' row length)
+    int M, P, Q;
+    int splits, kt_per_split;    // in K-tiles of 128 tokens
+    int direct;
+};
+
+constexpr int BK8 = 128;
+
+// the four transposed reads of one fragment: one address register, the other three rows 8 / 64 / 72 tile rows further as instruction
+// offsets (STEP = 8 rows in bytes: 1024 on the 128-byte rows of A, 2048 on the 256-byte rows of B)
+template <int STEP>
+__device__ __forceinline__ i32x8 lds_read_tr8_quad_raw(uint32_t a) {
+    v2i32_t r0, r1, r2, r3;
+    asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(r0) : "v"(a));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r1) : "v"(a), "n"(STEP));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r2) : "v"(a), "n"(8 * STEP));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r3) : "v"(a), "n"(9 * STEP));
+    return i32x8{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+}
+__device__ __forceinline__ void lds_raw_use8(i32x8& f) { asm volatile("" : "+v"(f)); }
+
+__device__ __forceinline__ int tn8_swz_a(int m) { return ((m >> 1) & 3) | (((m >> 4) & 1) << 2); }
+__device__ __forceinline__ int tn8_swz_b(int m) { return (m & 7) | (((m >> 4) & 1) << 3); }
+
+__global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wl = wave & 3;
+
+    const int ntq = (p.Q + TQ - 1) / TQ, ntp = (p.P + TP - 1) / TP;
+    const int ntiles = ntp * ntq;
+    const int bid = xcd_remap((int)blockIdx.x, ntiles * p.splits);
+    const int split = bid / ntiles, tile = bid % ntiles;
+    const int tp = tile / ntq, tq = tile % ntq;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int nk_total = (p.M + BK8 - 1) / BK8;
+    const int kt0 = split * p.kt_per_split;
+    int nk = nk_total - kt0;
+    if (nk > p.kt_per_split) nk = p.kt_per_split;
+    const int mbeg = kt0 * BK8;
+
+    const uint8_t* Ab = p.A + (int64_t)mbeg * p.lda + p0 + grp * 128;
+    const uint8_t* Bb = p.B + (int64_t)mbeg * p.ldb + q0;
+    int64_t a_bytes = (int64_t)(p.M - mbeg) * p.lda - p0 - grp * 128;
+    int64_t b_bytes = (int64_t)(p.M - mbeg) * p.ldb - q0;
+    if (a_bytes < 0) a_bytes = 0;
+    if (b_bytes < 0) b_bytes = 0;
+    const auto rsA = make_rsrc(Ab, (uint32_t)(a_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_bytes));
+    const auto rsB = make_rsrc(Bb, (uint32_t)(b_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : b_bytes));
+
+    // DMA.  A: one instruction = 8 tile rows x 128 B; wave wl of a group fills rows wl*32 .. wl*32+31 of the group's stage.
+    //       B: one instruction = 4 tile rows x 256 B; wave w fills rows w*16 .. w*16+15 of the slot (group 0: 0-63, group 1: 64-127).
+    // (piece i of a wave lies i * 8 rows (A) / i * 4 rows (B) below piece 0 -- a scalar offset -- and its swizzle differs from piece
+    // 0's in chunk bit 2 alone: pieces 2, 3 of A and pieces 1, 3 of B; two address registers per operand instead of four)
+    const int ma0 = wl * 32 + (lane >> 3), mb0 = wave * 16 + (lane >> 4);
+    const uint32_t voffA0 = (uint32_t)(ma0 * p.lda + (((lane & 7) ^ tn8_swz_a(ma0)) << 4)), voffA2 = voffA0 ^ 64u;
+    const uint32_t voffB0 = (uint32_t)(mb0 * p.ldb + (((lane & 15) ^ tn8_swz_b(mb0)) << 4)), voffB1 = voffB0 ^ 64u;
+    const uint32_t kstepA = (uint32_t)(BK8 * p.lda), kstepB = (uint32_t)(BK8 * p.ldb);
+    const uint32_t pieceA = (uint32_t)(8 * p.lda), pieceB = (uint32_t)(4 * p.ldb);
+    char* const ldsA = smem + grp * (2 * PP_A_STAGE) + wl * 4096;
+    char* const ldsB = smem + PP_B_BASE + wave * 4096;
+    auto fill_a = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            lds_dma16(rsA, ldsA + stage * PP_A_STAGE + i * 1024, i < 2 ? voffA0 : voffA2, (uint32_t)kt * kstepA + (uint32_t)i * pieceA);
+    };
+    auto fill_b = [&](int slot, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            lds_dma16(rsB, ldsB + slot * PP_B_SLOT + i * 1024, (i & 1) ? voffB1 : voffB0, (uint32_t)kt * kstepB + (uint32_t)i * pieceB);
+    };
+
+    // transposed fragment reads: read n of a fragment takes tile rows kb_n + 0..7, kb_n = 64 (n >> 1) + 16 qd + 8 (n & 1); the
+    // swizzle term is the same for the four (it depends on m[2:1] / m[2:0] and m[4] = qd & 1 only)
+    const int qd = lane >> 4, rq = (lane & 15) >> 1, rh = lane & 1;
+    const int m_rd = 16 * qd + rq;
+    const uint32_t rdA = (uint32_t)(m_rd * 128 + (tn8_swz_a(m_rd) << 4) + rh * 8);
+    const uint32_t rdB = (uint32_t)(m_rd * 256 + (tn8_swz_b(m_rd) << 4) + rh * 8);
+    const uint32_t lds0 = lds_offset(smem);
+    const uint32_t baseA = lds0 + (uint32_t)(grp * (2 * PP_A_STAGE)), baseB = lds0 + (uint32_t)PP_B_BASE;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // block scales of one K-tile: A -> byte (i >> 1) of a dword, B -> byte (j >> 1)
+    const int ktpr_a = (int)(p.lda >> 7), ktpr_b = (int)(p.ldb >> 7);
+    const int ca = (p0 + grp * 128) >> 7;                    // the group's 128-column group of A
+    const int kb_b = (q0 + wl * 64) >> 5;                    // the wave's first 32-column block of B (even)
+    const bool a_cols_ok = p0 + grp * 128 < p.P, b_cols_ok = q0 + wl * 64 < p.Q;
+    // (the six dwords a lane needs -- byte 2 qd of the 8-byte words of its four / two column blocks -- are requested as six dword loads
+    // and kept RAW until the K-tile's last barrier: `scales_ready` is the first use the compiler sees, so its vmcnt wait lands behind the
+    // counted waits that have retired the loads anyway.  Used where they are requested, the loads' full latency -- they are the only
+    // HBM round trip of the loop that is not an LDS-DMA -- stood in front of every K-tile's first MFMA: 1755 against 1196 us per launch
+    // at [323584, 1024] x [323584, 4096].)
+    const int sh = 16 * (qd & 1), hi = qd >> 1;
+    struct RawScales { uint32_t a[4], b[2]; };
+    auto request_scales = [&](int kt_global, RawScales& r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.a[k] = 0x7F7F7F7Fu;
+        r.b[0] = r.b[1] = 0x7F7F7F7Fu;
+        if (kt_global * BK8 + 32 * qd < p.M) {
+            if (a_cols_ok) {
+                const uint32_t* g = (const uint32_t*)(p.sa + ((int64_t)kt_global * ktpr_a + ca) * 512) + hi;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r.a[k] = g[2 * k];
+            }
+            if (b_cols_ok) {
+                const uint32_t* g = (const uint32_t*)(p.sb + ((int64_t)kt_global * ktpr_b + (kb_b >> 2)) * 512 + (kb_b & 3) * 8) + hi;
+                r.b[0] = g[0]; r.b[1] = g[2];
+            }
+        }
+    };
+    auto scales_ready = [&](RawScales& r, uint32_t& sa_out, uint32_t& sb_out) {
+        asm volatile("" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]));
+        sa_out = ((r.a[0] >> sh) & 255u) | (((r.a[1] >> sh) & 255u) << 8) | (((r.a[2] >> sh) & 255u) << 16) | (((r.a[3] >> sh) & 255u) << 24);
+        sb_out = ((r.b[0] >> sh) & 255u) | (((r.b[1] >> sh) & 255u) << 8);
+    };
+
+    i32x8 fq[4];
+    uint32_t sav = 0x7F7F7F7Fu, sbv = 0x7F7F7F7Fu, sav_n = 0x7F7F7F7Fu, sbv_n = 0x7F7F7F7Fu;
+    RawScales raw;
+#define VIPANT_TN8_MX(ACC, BF, AF, OB, OA) \
+    ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(BF, AF, ACC, 0, 0, OB, (int)sbv, OA, (int)sav)
+    // row tiles 4 h .. 4 h + 3 of the wave (h = 0: the B fragments are read first and kept)
+    auto half_ktile = [&](auto hc, uint32_t tA, uint32_t tB) {
+        constexpr int h = decltype(hc)::value;
+        i32x8 fp[2];
+        auto fragA = [&](int cb) { return lds_read_tr8_quad_raw<1024>(tA + (rdA ^ (uint32_t)(cb << 4))); };
+        auto fragB = [&](int cb) { return lds_read_tr8_quad_raw<2048>(tB + (rdB ^ (uint32_t)(cb << 4))); };
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fq[j] = fragB(wl * 4 + j);
+        }
+        fp[0] = fragA(h * 4 + 0);
+        // the A fragments run one row tile (four MFMAs, 128 cycles) ahead
+#define VIPANT_TN8_ROW(T)                                                                           \
+        if (T + 1 < 4) fp[(T + 1) & 1] = fragA(h * 4 + T + 1);                                      \
+        if (T + 1 < 4) lds_raw_wait<4>(); else lds_raw_wait<0>();                                   \
+        lds_raw_use8(fp[T & 1]);                                                                    \
+        if (T == 0 && h == 0) { lds_raw_use8(fq[0]); lds_raw_use8(fq[1]); lds_raw_use8(fq[2]); lds_raw_use8(fq[3]); } \
+        VIPANT_TN8_MX(acc[h * 4 + T][0], fq[0], fp[T & 1], 0, (h * 4 + T) >> 1);                    \
+        VIPANT_TN8_MX(acc[h * 4 + T][1], fq[1], fp[T & 1], 0, (h * 4 + T) >> 1);                    \
+        VIPANT_TN8_MX(acc[h * 4 + T][2], fq[2], fp[T & 1], 1, (h * 4 + T) >> 1);                    \
+        VIPANT_TN8_MX(acc[h * 4 + T][3], fq[3], fp[T & 1], 1, (h * 4 + T) >> 1);                    \
+        __builtin_amdgcn_sched_barrier(0);
+        VIPANT_TN8_ROW(0) VIPANT_TN8_ROW(1) VIPANT_TN8_ROW(2) VIPANT_TN8_ROW(3)
+#undef VIPANT_TN8_ROW
+    };
+
+    // prologue: scales and K-tile 0 (and, for group 1, its B rows of K-tile 1)
+    request_scales(kt0, raw);
+    scales_ready(raw, sav, sbv);                             // awaited before any DMA is in flight
+    fill_a(0, 0);
+    fill_b(0, 0);
+    if (grp == 1) {
+        fill_b(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // the lag
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        const uint32_t tA = baseA + (uint32_t)(stage * PP_A_STAGE), tB = baseB + (uint32_t)(slot * PP_B_SLOT);
+        request_scales(kt0 + kt + 1, raw);               // older than this K-tile's DMA pieces
+        fill_a(stage ^ 1, kt + 1);
+        if (grp == 0) fill_b(slot1, kt + 1); else fill_b(slot2, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        half_ktile(Int<0>{}, tA, tB);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // the next K-tile's scales: requested in front of this K-tile's eight DMA pieces, first used here -- the wait the compiler
+        // puts in front of this is vmcnt(8), which leaves those pieces in flight (at the K-tile's end it was vmcnt(0))
+        scales_ready(raw, sav_n, sbv_n);
+        half_ktile(Int<1>{}, tA, tB);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = slot1;
+        sav = sav_n; sbv = sbv_n;
+    }
+#undef VIPANT_TN8_MX
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
+    // lane holds C[p = p0 + grp*128 + i*16 + (lane&15)][q = q0 + wl*64 + j*16 + (lane>>4)*4 + 0..3]
+    const int frow = lane & 15, g = lane >> 4;
+    if (p.direct) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = p0 + grp * 128 + i * 16 + frow;
+            if (pr >= p.P) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qc = q0 + wl * 64 + j * 16 + g * 4;
+                if (qc < p.Q) *(f32x4*)(p.out + (int64_t)pr * p.ldo + qc) = acc[i][j];
+            }
+        }
+    } else {
+        float* slab = p.out + ((int64_t)split * ntiles + tile) * (TP * TQ);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4*)(slab + (grp * 128 + i * 16 + frow) * TQ + wl * 64 + j * 16 + g * 4) = acc[i][j];
+    }
+}
+
 __device__ __forceinline__ void tn_reduce_blocks(const float* slab, float* C, int64_t ldc, int P, int Q, int splits, int accumulate,
                                                  int block, int nblocks) {
     const int ntq = (Q + TQ - 1) / TQ, ntp = (P + TP - 1) / TP;
@@ -498,6 +741,18 @@ void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
     *kt_per_split = (int)per;
 }
 
+// the e4m3 kernel: K-tiles of 128 tokens
+void plan8(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
+    const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
+    const int64_t nk = ceil_div(M, BK8);
+    int64_t s = 256 / tiles;
+    if (s < 1) s = 1;
+    if (s > nk) s = nk;
+    const int64_t per = ceil_div(nk, s);
+    *splits = (int)ceil_div(nk, per);
+    *kt_per_split = (int)per;
+}
+
 }  // namespace
 
 extern "C" size_t vipant_gemm_tn_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
@@ -564,6 +819,54 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
     if (a_colsum != nullptr) {
         hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 64)), dim3(256), 0, s,
                            (const float*)cs_part, a_colsum, (int)P, cs_stride, cs_parts, accumulate);
+        VIPANT_LAUNCH_CHECK();
+    }
+    return VIPANT_OK;
+}
+
+// C[P, Q] (+)= dequant(A, sa)^T dequant(B, sb) on e4m3 operands whose MX scales are uniform over 32-token x 32-column blocks.
+extern "C" size_t vipant_gemm_tn_e4m3_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
+    int splits, per;
+    plan8(M, P, Q, &splits, &per);
+    return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float);
+}
+
+extern "C" int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb,
+                                       float* C, int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    VIPANT_REQUIRE(M > 0 && P > 0 && Q > 0, VIPANT_EBADSHAPE, "gemm_tn_e4m3: empty problem");
+    VIPANT_REQUIRE(P % 128 == 0 && Q % 128 == 0, VIPANT_EBADSHAPE, "gemm_tn_e4m3: need P %% 128 == 0 and Q %% 128 == 0 (P=%ld Q=%ld)",
+                   (long)P, (long)Q);
+    VIPANT_REQUIRE(lda >= P && ldb >= Q && ldc >= Q && lda % 128 == 0 && ldb % 128 == 0 && ldc % 4 == 0, VIPANT_EALIGN,
+                   "gemm_tn_e4m3: bad leading dims (lda, ldb: the full row length of the quantised matrices, a multiple of 128)");
+    VIPANT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)sa % 16 == 0) &&
+                       ((uintptr_t)sb % 16 == 0) && sa != nullptr && sb != nullptr,
+                   VIPANT_EALIGN, "gemm_tn_e4m3: operands and their block scales must be 16-byte aligned");
+    int splits, per;
+    plan8(M, P, Q, &splits, &per);
+    VIPANT_REQUIRE((int64_t)(per + 3) * BK8 * (lda > ldb ? lda : ldb) < (1ll << 32), VIPANT_EBADSHAPE,
+                   "gemm_tn_e4m3: per-split byte range exceeds 4 GiB");
+    const size_t need = vipant_gemm_tn_e4m3_workspace_bytes(M, P, Q);
+    const int direct = (splits == 1 && !accumulate) ? 1 : 0;
+    if (!direct)
+        VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= need, VIPANT_ENOWORKSPACE,
+                       "gemm_tn_e4m3: workspace too small (%zu < %zu)", workspace_bytes, need);
+    static DeviceOnce once;
+    if (first_on_device(once)) {
+        VIPANT_HIP_TRY(hipFuncSetAttribute((const void*)gemm_tn8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+        done_on_device(once);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
+    GemmTN8 p{A, B, sa, sb, direct ? C : (float*)workspace, lda, ldb, direct ? ldc : TQ, (int)M, (int)P, (int)Q, splits, per, direct};
+    hipLaunchKernelGGL(gemm_tn8_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(512), PP_LDS_BYTES, s, p);
+    VIPANT_LAUNCH_CHECK();
+    if (!direct) {
+        const int64_t total4 = tiles * TP * TQ / 4;
+        int blocks = (int)ceil_div(total4, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)P, (int)Q, splits,
+                           accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;

@@ -122,6 +122,41 @@ def quant_e4m3_mx(x: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor =
     return q, scale
 
 
+def quant_e4m3_mx32(x: torch.Tensor, q: torch.Tensor = None, scale: torch.Tensor = None):
+    """bf16 rows [M, K] -> (e4m3 bytes, block scales in the MX layout) with every scale shared by an aligned block of 32 rows x 32
+    columns (vipant_quant_e4m3_mx32): an operand of gemm_tn_e4m3, and as valid an activation operand of gemm_nt_e4m3 as any."""
+    _need(x, BF16, "quant_e4m3_mx32.x")
+    M, K = x.shape
+    if q is None:
+        q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((query("vipant_mx_scale_bytes", M, K),), dtype=torch.uint8, device=x.device)
+    call("vipant_quant_e4m3_mx32", x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), M, K, _stream())
+    return q, scale
+
+
+def mx_uniform32(q: torch.Tensor, scale: torch.Tensor):
+    """In place: e4m3 bytes [M, K] with row-wise block scales -> block-uniform scales (vipant_mx_uniform32)."""
+    assert q.dtype == torch.uint8 and scale.dtype == torch.uint8 and q.dim() == 2
+    M, K = q.shape
+    assert scale.numel() >= query("vipant_mx_scale_bytes", M, K)
+    call("vipant_mx_uniform32", q.data_ptr(), q.stride(0), scale.data_ptr(), M, K, _stream())
+    return q, scale
+
+
+def gemm_tn_e4m3(a, sa, b, sb, c: torch.Tensor, accumulate: bool = False, ws_name: str = "gemm_tn"):
+    """c[P, Q] (fp32) (+)= dequant(a, sa)^T @ dequant(b, sb): a [M, P], b [M, Q] e4m3 bytes with block-uniform scales."""
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and sa.dtype == torch.uint8 and sb.dtype == torch.uint8
+    _need(c, F32, "gemm_tn_e4m3.c")
+    M, P = a.shape
+    Q = b.shape[1]
+    assert b.shape[0] == M and tuple(c.shape) == (P, Q), (a.shape, b.shape, c.shape)
+    ws = scratch(ws_name, query("vipant_gemm_tn_e4m3_workspace_bytes", M, P, Q), a.device)
+    call("vipant_gemm_tn_e4m3", a.data_ptr(), a.stride(0), sa.data_ptr(), b.data_ptr(), b.stride(0), sb.data_ptr(), c.data_ptr(),
+         c.stride(0), M, P, Q, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return c
+
+
 def mx_scale_index(M: int, K: int, device) -> torch.Tensor:
     """int64 [M, K // 32]: where the MX layout keeps the scale byte of (row, 32-element block) -- for tests and tools."""
     m = torch.arange(M, device=device).view(M, 1)
