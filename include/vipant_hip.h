@@ -419,6 +419,17 @@ typedef struct vipant_fp8_plan {
      * quantisation pass); an operator that produces a new stream gradient (its LayerNorm backward) writes the new one's there. */
     uint8_t* dy_q;
     uint8_t* dy_scale;
+    /* round 6, backward operators: tn_e4m3 != 0 -- the operator's WEIGHT-GRADIENT contractions run on e4m3 operands too
+     * (vipant_gemm_tn_e4m3; emit_q / emit_scale are then required as a second scratch).  Operands whose e4m3 form the operator has at
+     * hand (dy_q; du in emit_q; dqkv in act_q) are made block-uniform in place (vipant_mx_uniform32); the kept forward activation
+     * -- g (MLP), the attention output (out_proj), ln_1's output (in_proj) -- is read from keep_q / keep_scale, ln_2's output from
+     * keep2_q / keep2_scale, if the forward kept their block-uniform e4m3 forms, and is otherwise quantised from the bf16 argument
+     * (vipant_quant_e4m3_mx32) into scratch.  Bias gradients (in_proj, c_fc) then come from vipant_colsum_bf16. */
+    int64_t tn_e4m3;
+    const uint8_t* keep_q;
+    const uint8_t* keep_scale;
+    const uint8_t* keep2_q;
+    const uint8_t* keep2_scale;
 } vipant_fp8_plan;
 /* LayerNorm with the block quantisation of its bf16 output fused (the row is in registers anyway): q bytes [M, D] / qscale bytes
  * [vipant_mx_scale_bytes(M, D)] = vipant_quant_e4m3_mx of y resp. dx_bf16, bit for bit; both NULL: exactly vipant_layernorm_fwd /

@@ -29,7 +29,8 @@ _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_siz
 class Fp8Plan(C.Structure):
     """struct vipant_fp8_plan (include/vipant_hip.h): e4m3 weights + activation scratch of one fused block operator call."""
     _fields_ = [("w_q", _p), ("w_scale", _p), ("w2_q", _p), ("w2_scale", _p), ("act_q", _p), ("act_scale", _p),
-                ("emit_q", _p), ("emit_scale", _p), ("dy_q", _p), ("dy_scale", _p)]
+                ("emit_q", _p), ("emit_scale", _p), ("dy_q", _p), ("dy_scale", _p), ("tn_e4m3", _i64), ("keep_q", _p), ("keep_scale", _p),
+                ("keep2_q", _p), ("keep2_scale", _p)]
 
 
 # name -> (restype, argtypes); mirrors include/vipant_hip.h one to one

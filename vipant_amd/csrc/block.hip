@@ -54,6 +54,27 @@ int32_t ln_bwd(const vipant_fp8_plan* plan, const uint16_t* dh, const void* x, i
                                      D, workspace, workspace_bytes, q, qs, stream);
 }
 
+// Do this operator's weight-gradient contractions run on e4m3 operands?  (The plan asks for it, the second scratch is there, and the
+// shapes are the kernel's: every operand width a multiple of 128.)
+bool tn8(const vipant_fp8_plan* plan, int64_t D) {
+    return plan != nullptr && plan->tn_e4m3 != 0 && plan->emit_q != nullptr && plan->emit_scale != nullptr && D % 128 == 0;
+}
+
+// One operand [M, K] of vipant_gemm_tn_e4m3 in block-uniform form: (q, s) given and row-wise -> made uniform in place; given and
+// `uniform` -> as they are; not given -> quantised from the bf16 matrix into (scratch_q, scratch_s).
+int32_t operand8(uint8_t* q, uint8_t* s, bool uniform, const uint16_t* bf16_src, uint8_t* scratch_q, uint8_t* scratch_s, int64_t M,
+                 int64_t K, const uint8_t** out_q, const uint8_t** out_s, void* stream) {
+    if (q != nullptr && s != nullptr) {
+        if (!uniform) TRY(vipant_mx_uniform32(q, K, s, M, K, stream));
+        *out_q = q; *out_s = s;
+        return VIPANT_OK;
+    }
+    VIPANT_REQUIRE(bf16_src != nullptr, VIPANT_EBADSHAPE, "fp8 plan: a weight-gradient operand is neither kept in e4m3 nor given in bf16");
+    TRY(vipant_quant_e4m3_mx32(bf16_src, K, scratch_q, K, scratch_s, M, K, stream));
+    *out_q = scratch_q; *out_s = scratch_s;
+    return VIPANT_OK;
+}
+
 }  // namespace
 
 extern "C" size_t vipant_block_workspace_bytes(int64_t M, int64_t D) {
@@ -61,6 +82,7 @@ extern "C" size_t vipant_block_workspace_bytes(int64_t M, int64_t D) {
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, 4 * D, D));
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, 4 * D));
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, D));
+    w = max_sz(w, vipant_colsum_workspace_bytes(M, 4 * D));         // e4m3 weight gradients: the bias gradients' own pass
     return max_sz(w, vipant_layernorm_bwd_workspace_bytes(M, D));
 }
 
@@ -96,7 +118,17 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, preq ? plan->act_q : nullptr,
            preq ? plan->act_scale : nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M, D, 3 * D, VIPANT_EPI_BF16, stream));
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
-    TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
+    if (tn8(plan, D)) {
+        const uint8_t *aq, *as, *bq, *bs;
+        // (dqkv's row-wise e4m3 form is in the plan's scratch either way: left there by vipant_mha_bwd_e4m3, or by the contraction above)
+        TRY(operand8(plan->act_q, plan->act_scale, false, dqkv, nullptr, nullptr, M, 3 * D, &aq, &as, stream));
+        TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, h, plan->emit_q, plan->emit_scale,
+                     M, D, &bq, &bs, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, 3 * D, as, bq, D, bs, dw, D, M, 3 * D, D, 0, workspace, workspace_bytes, stream));
+        TRY(vipant_colsum_bf16(dqkv, 3 * D, db, M, 3 * D, 0, workspace, workspace_bytes, stream));
+    } else {
+        TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
+    }
     // ln_1 backward + residual-gradient add, in place on the stream gradient (fp32 master + bf16 copy, or bf16 only)
     return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,
                   workspace_bytes, stream);
@@ -142,6 +174,13 @@ extern "C" int32_t vipant_gemm_bias_residual_bwd_e4m3(const uint16_t* dy, const 
     // da[M, K] = dy[M, N] . W[N, K]   (w_t is W^T, [K, N]);  dW[N, K] = dy^T a
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
            plan ? plan->dy_scale : nullptr, dy, w_t, da, nullptr, nullptr, M, K, N, VIPANT_EPI_BF16, stream));
+    if (tn8(plan, N) && K % 128 == 0 && plan->dy_q != nullptr) {
+        const uint8_t *aq, *as, *bq, *bs;
+        TRY(operand8(plan->dy_q, plan->dy_scale, false, dy, nullptr, nullptr, M, N, &aq, &as, stream));
+        TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, a, plan->act_q, plan->act_scale, M,
+                     K, &bq, &bs, stream));
+        return vipant_gemm_tn_e4m3(aq, N, as, bq, K, bs, dw, K, M, N, K, 0, workspace, workspace_bytes, stream);
+    }
     return vipant_gemm_tn(dy, N, a, K, dw, K, M, N, K, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -222,8 +261,22 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
     // 256 MB cache.)
     TRY(nt(plan, plan ? plan->w2_q : nullptr, plan ? plan->w2_scale : nullptr, emit ? plan->emit_q : nullptr,
            emit ? plan->emit_scale : nullptr, du, w_fc_t, dh, nullptr, nullptr, M, D, 4 * D, VIPANT_EPI_BF16 | few, stream));
-    TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
-    TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
+    if (tn8(plan, D) && plan->dy_q != nullptr) {
+        // (every operand's e4m3 form has served its NT contraction by now -- stream order -- and may change in place)
+        const uint8_t *aq, *as, *bq, *bs;
+        TRY(operand8(plan->dy_q, plan->dy_scale, false, dy, nullptr, nullptr, M, D, &aq, &as, stream));
+        TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, g, plan->act_q, plan->act_scale, M,
+                     4 * D, &bq, &bs, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, D, as, bq, 4 * D, bs, dw_proj, 4 * D, M, D, 4 * D, 0, workspace, workspace_bytes, stream));
+        TRY(operand8(plan->emit_q, plan->emit_scale, false, du, nullptr, nullptr, M, 4 * D, &aq, &as, stream));
+        TRY(operand8(const_cast<uint8_t*>(plan->keep2_q), const_cast<uint8_t*>(plan->keep2_scale), true, h, plan->act_q, plan->act_scale,
+                     M, D, &bq, &bs, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, 4 * D, as, bq, D, bs, dw_fc, D, M, 4 * D, D, 0, workspace, workspace_bytes, stream));
+        TRY(vipant_colsum_bf16(du, 4 * D, db_fc, M, 4 * D, 0, workspace, workspace_bytes, stream));
+    } else {
+        TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
+        TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
+    }
     // ln_2 backward + residual-gradient add, in place; its dx is also d(out_proj output): dx_colsum = d out_proj.bias
     return ln_bwd(plan, dh, x, stream_flags, mean, rstd, gamma, dstream, dx_bf16, dgamma, dbeta, dx_colsum, M, D, workspace,
                   workspace_bytes, stream);

@@ -165,12 +165,16 @@ __device__ __forceinline__ uint32_t mx_lane_max_u(uint32_t v) {
     return v;
 }
 // the block's maximum |.| as bf16 bits -> its scale byte (E8M0) and the float 2^e the conversion divides by
+// (round 6: an ALL-ZERO block carries the smallest scale there is, byte 0 = 2^-127, and converts with 2^0 -- not byte 127 as a block
+// whose largest element is ~1 does: vipant_mx_uniform32 takes the maximum of 32 rows' scales, and a row of zeros -- 960 of the 992 rows
+// of the top block's stream gradient in a step whose read-out takes one row per item -- must not set it)
 __device__ __forceinline__ uint32_t mx_scale_of_max(uint32_t m, float* scale) {
-    int e = 0;
-    if (m != 0u) {
-        e = (int)(m >> 7) - 127 - 8 + ((m & 0x7Fu) > 0x60u ? 1 : 0);
-        e = e < -127 ? -127 : e;                    // (a bf16 below 2^127 never needs e > 119)
+    if (m == 0u) {
+        *scale = 1.0f;
+        return 0u;
     }
+    int e = (int)(m >> 7) - 127 - 8 + ((m & 0x7Fu) > 0x60u ? 1 : 0);
+    e = e < -127 ? -127 : e;                        // (a bf16 below 2^127 never needs e > 119)
     const uint32_t byte = (uint32_t)(e + 127);
     *scale = __uint_as_float(byte ? byte << 23 : 0x00400000u);          // 2^e (2^-127 is a subnormal)
     return byte;

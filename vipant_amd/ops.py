@@ -360,14 +360,21 @@ def cast_weights(weights: Sequence[torch.Tensor], e4m3: bool = False):
     return wb, wt
 
 
-def fp8_plan(w=None, w2=None, act=None, dyq=None, emit=None):
+FP8_TN = os.environ.get("VIPANT_FP8_TN", "1") != "0"      # e4m3 towers: the weight-gradient contractions on e4m3 operands too (0: bf16, the round-5 form)
+
+
+def fp8_plan(w=None, w2=None, act=None, dyq=None, emit=None, tn=False, keep=None, keep2=None):
     """struct vipant_fp8_plan for one fused-operator call: w / w2 = (bytes, row scales) of the operator's weights, act = (scratch
     bytes [M, 4D], its block scales), emit = the same pair for the e4m3 form an MLP operator's first contraction leaves for its
-    second, dyq = (bytes [M, D], block scales): the quantised stream gradient that travels between the backward operators."""
+    second, dyq = (bytes [M, D], block scales): the quantised stream gradient that travels between the backward operators;
+    tn: the operator's weight-gradient contractions run on e4m3 operands; keep / keep2: block-uniform e4m3 forms of its kept forward
+    activations."""
     from ._ffi import Fp8Plan
     return Fp8Plan(w[0].data_ptr(), w[1].data_ptr(), w2[0].data_ptr() if w2 else None, w2[1].data_ptr() if w2 else None,
                    act[0].data_ptr(), act[1].data_ptr(), emit[0].data_ptr() if emit else None, emit[1].data_ptr() if emit else None,
-                   dyq[0].data_ptr() if dyq else None, dyq[1].data_ptr() if dyq else None)
+                   dyq[0].data_ptr() if dyq else None, dyq[1].data_ptr() if dyq else None, int(bool(tn)),
+                   keep[0].data_ptr() if keep else None, keep[1].data_ptr() if keep else None,
+                   keep2[0].data_ptr() if keep2 else None, keep2[1].data_ptr() if keep2 else None)
 
 
 def fp8_scratch(M: int, D: int, device):
@@ -933,18 +940,18 @@ class BackboneFn(torch.autograd.Function):
                  h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
                  du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq, emit=emit)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
-                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq)) if fp8 else None, st)
+                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None, st)
             q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal, q8=q8)
             call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[0], None, act, dyq)) if fp8 else None,
+                 C.byref(fp8_plan(wtq4[0], None, act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None,
                  (_ffi.STREAM_IN_F16 if x.dtype == F16 else 0) | (_ffi.STREAM_ACT_Q if q8 else 0), st)
             del dqkv
             for i, v in enumerate(lg.views):
