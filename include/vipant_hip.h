@@ -229,11 +229,12 @@ int32_t vipant_mx_uniform32(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, 
 /* Weight-gradient contraction on e4m3 operands (BASELINE.json configs[4]; the autograd of nn.Linear weight, cvap/module/val.py:500-506,
  * as vipant_gemm_tn): C[P, Q] fp32 (+)= dequant(A, sa)^T dequant(B, sb), reduction over the token dimension M.  A [M, P], B [M, Q]:
  * token-major e4m3 bytes with block-uniform scales (above); lda / ldb = the row length of the quantised matrices (what their scale
- * layouts were written with), P and Q multiples of 128.  fp32 accumulation, deterministic split over M through `workspace`. */
+ * layouts were written with), P and Q multiples of 128.  fp32 accumulation, deterministic split over M through `workspace`.
+ * a_colsum (optional fp32 [P]) (+)= sum_m dequant(A)[m, p], taken from the A tiles while they sit in LDS, as in vipant_gemm_tn. */
 size_t vipant_gemm_tn_e4m3_workspace_bytes(int64_t M, int64_t P, int64_t Q);
 int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb, float* C,
-                            int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                            void* stream);
+                            int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum, void* workspace,
+                            size_t workspace_bytes, void* stream);
 /* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result -- vipant_quant_e4m3_mx of `out`
  * [M, D] resp. `dqkv` [M, 3 D], bit for bit -- for the contraction that follows (out_proj; in_proj^T).  No reference counterpart
  * (BASELINE.json configs[4]).  The streamed single-pass backward (224 < S <= 320, no mask) emits the dK | dV columns from its own
@@ -424,7 +425,7 @@ typedef struct vipant_fp8_plan {
      * hand (dy_q; du in emit_q; dqkv in act_q) are made block-uniform in place (vipant_mx_uniform32); the kept forward activation
      * -- g (MLP), the attention output (out_proj), ln_1's output (in_proj) -- is read from keep_q / keep_scale, ln_2's output from
      * keep2_q / keep2_scale, if the forward kept their block-uniform e4m3 forms, and is otherwise quantised from the bf16 argument
-     * (vipant_quant_e4m3_mx32) into scratch.  Bias gradients (in_proj, c_fc) then come from vipant_colsum_bf16. */
+     * (vipant_quant_e4m3_mx32) into scratch.  The bias gradients (in_proj, c_fc) ride on the contraction as in the bf16 operators. */
     int64_t tn_e4m3;
     const uint8_t* keep_q;
     const uint8_t* keep_scale;

@@ -168,8 +168,12 @@ def test_e4m3_weight_gradient_contraction_is_exact_on_its_operands(ops, M, P, Q)
     err = float((c.double() - ref).abs().max() / scale)
     assert err < 4e-4, err
     c2 = c.clone()
-    ops.gemm_tn_e4m3(qa, sa, qb, sb, c2, accumulate=True)
+    cs = torch.zeros(P, device=DEV)                       # (accumulate applies to the column sums too)
+    ops.gemm_tn_e4m3(qa, sa, qb, sb, c2, accumulate=True, a_colsum=cs)
     assert float((c2.double() - 2 * c.double()).abs().max() / scale) < 1e-6            # the accumulate path itself is fp32-exact
+    # the column sums of dequant(A) that ride along (the bias gradient of the same Linear): fp32 sums of exactly representable terms
+    cs_ref = dequant_mx(ops, qa, sa).double().sum(dim=0)
+    assert float((cs.double() - cs_ref).abs().max() / cs_ref.abs().max()) < 1e-5, float((cs.double() - cs_ref).abs().max() / cs_ref.abs().max())
     full = a.double().t() @ b.double()
     dist = float((c.double() - full).norm() / full.norm())
     print(f"e4m3 TN [{M}, {P}] x [{M}, {Q}]: {err:.2e} of the dequantised product's scale; {dist:.3e} rel-L2 from the unquantised product")
@@ -219,6 +223,28 @@ def test_e4m3_contraction_is_exact_on_its_operands(ops, M, N, K):
     assert float(dist) < 6e-2, float(dist)            # e4m3 x e4m3 on gaussian rows: ~2^-4 / sqrt(3) per factor, observed ~3.7e-2
 
 
+def check_block_uniform_form(ops, em, ref_bf16, slack):
+    """(bytes, scales) left by a producer for the bf16 matrix `ref_bf16`: scales uniform over aligned 32 x 32 blocks, never below
+    what the block's largest element needs (nothing saturates) and at most `slack` binades above it (the producers take the scale
+    from a bound they have in registers, not from the exact maximum), and the bytes exactly ref / 2^e rounded to e4m3."""
+    M, N = ref_bf16.shape
+    s = mx_scales(ops, em[1], M, N).int()
+    _, s_min = emulate_quant_mx32(ref_bf16)
+    Mp = (M + 31) // 32 * 32
+    pad = torch.zeros(Mp, N // 32, dtype=torch.int32, device=s.device); pad[:M] = s
+    pad[M:] = pad[(M - 1) // 32 * 32]                                  # rows beyond M: whatever the block has
+    blk = pad.view(Mp // 32, 32, N // 32)
+    assert torch.equal(blk.amax(dim=1), blk.amin(dim=1))                # one scale per block
+    nz = s_min.int() > 0
+    assert bool((s[nz] >= s_min.int()[nz]).all()) and bool((s[nz] <= s_min.int()[nz] + slack).all()), \
+        (int((s - s_min.int())[nz].min()), int((s - s_min.int())[nz].max()))
+    sc = torch.exp2(s.float() - 127)[:, :, None].expand(M, N // 32, 32).reshape(M, N)
+    want = (ref_bf16.float() / sc).to(torch.float8_e4m3fn).view(torch.uint8)
+    zero_blk = (~nz)[:, :, None].expand(M, N // 32, 32).reshape(M, N)
+    assert torch.equal(em[0][~zero_blk], want[~zero_blk])
+    print(f"block-uniform emit: scale - minimal scale: mean {float((s - s_min.int())[nz].float().mean()):.3f} binades")
+
+
 def test_e4m3_quickgelu_epilogues(ops):
     M, N, K = 1024, 3072, 768
     a = rnd(M, K, seed=5).to(torch.bfloat16)
@@ -235,11 +261,15 @@ def test_e4m3_quickgelu_epilogues(ops):
     em = (torch.full((M, N), 77, dtype=torch.uint8, device=DEV), torch.full((ops.query("vipant_mx_scale_bytes", M, N),), 77, dtype=torch.uint8, device=DEV))
     ops.gemm_nt_e4m3(qa, sa, qw, sw, g2, bias=bias, aux=code2, epi=ops.EPI_QUICKGELU_D8, emit=em)
     assert torch.equal(g, g2) and torch.equal(code, code2)
-    gq, gs = ops.quant_e4m3_mx(g)
-    assert torch.equal(em[0], gq) and torch.equal(mx_scales(ops, em[1], M, N), mx_scales(ops, gs, M, N))
+    check_block_uniform_form(ops, em, g, slack=2)
+    # ... alone (`running.recompute_mlp`: g and the codes are not wanted at all), and with the codes but without g (round 6: what the
+    # forward of a tower with e4m3 weight gradients keeps): the same bytes and scales
     em2 = (torch.full_like(em[0], 78), torch.full_like(em[1], 78))
     ops.gemm_nt_e4m3(qa, sa, qw, sw, None, bias=bias, epi=ops.EPI_QUICKGELU_D8, emit=em2)
-    assert torch.equal(em2[0], gq) and torch.equal(mx_scales(ops, em2[1], M, N), mx_scales(ops, gs, M, N))
+    assert torch.equal(em2[0], em[0]) and torch.equal(mx_scales(ops, em2[1], M, N), mx_scales(ops, em[1], M, N))
+    em4, code4 = (torch.full_like(em[0], 80), torch.full_like(em[1], 80)), torch.empty_like(code)
+    ops.gemm_nt_e4m3(qa, sa, qw, sw, None, bias=bias, aux=code4, epi=ops.EPI_QUICKGELU_D8, emit=em4)
+    assert torch.equal(em4[0], em[0]) and torch.equal(mx_scales(ops, em4[1], M, N), mx_scales(ops, em[1], M, N)) and torch.equal(code4, code)
     u = (dequant_mx(ops, qa, sa).double() @ dequant(qw, sw).double().t() + bias.double()).float()
     ub = u.to(torch.bfloat16).float()                                             # the epilogue sees the bf16-rounded pre-activation
     sg = torch.sigmoid(1.702 * ub)
@@ -258,8 +288,11 @@ def test_e4m3_quickgelu_epilogues(ops):
     du2 = torch.empty_like(du)
     em3 = (torch.full_like(em[0], 79), torch.full_like(em[1], 79))
     ops.gemm_nt_e4m3(qd, sd, qw, sw, du2, aux=code, epi=ops.EPI_DQUICKGELU_D8, emit=em3)          # ... and du's e4m3 form beside du
-    dq, ds = ops.quant_e4m3_mx(du)
-    assert torch.equal(du, du2) and torch.equal(em3[0], dq) and torch.equal(mx_scales(ops, em3[1], M, N), mx_scales(ops, ds, M, N))
+    assert torch.equal(du, du2)
+    check_block_uniform_form(ops, em3, du, slack=2)
+    em5 = (torch.full_like(em[0], 81), torch.full_like(em[1], 81))
+    ops.gemm_nt_e4m3(qd, sd, qw, sw, None, aux=code, epi=ops.EPI_DQUICKGELU_D8, emit=em5)        # ... and alone (round 6: nothing reads du's bf16 form)
+    assert torch.equal(em5[0], em3[0]) and torch.equal(mx_scales(ops, em5[1], M, N), mx_scales(ops, em3[1], M, N))
 
 
 def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
@@ -311,8 +344,8 @@ def test_block_stack_with_e4m3_contractions_tracks_the_bf16_stack(ops):
 
 @pytest.mark.parametrize("D", [768, 1024])
 def test_layernorm_fused_block_quantisation_is_the_standalone_one(ops, D):
-    """vipant_layernorm_{fwd,bwd}_e4m3: the bytes and block scales written beside the bf16 output are exactly what
-    vipant_quant_e4m3_mx makes of that output (so fusing the pass changes nothing downstream)."""
+    """vipant_layernorm_bwd_e4m3: the bytes and block scales written beside the bf16 gradient are exactly what vipant_quant_e4m3_mx
+    makes of it (so fusing the pass changes nothing downstream); vipant_layernorm_fwd_e4m3: the stated static-scale form of its output."""
     M = 1000
     x = rnd(M, D, seed=31) * torch.exp2(torch.randint(-4, 5, (M, 1), device=DEV).float())
     add = rnd(M, D, seed=32).to(torch.bfloat16)
@@ -325,8 +358,14 @@ def test_layernorm_fused_block_quantisation_is_the_standalone_one(ops, D):
     st = torch.cuda.current_stream().cuda_stream
     ops.call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, mean.data_ptr(),
              rstd.data_ptr(), M, D, add.data_ptr(), xs.data_ptr(), q.data_ptr(), qs.data_ptr(), 0, st)
-    q_ref, s_ref = ops.quant_e4m3_mx(y)
-    assert torch.equal(q, q_ref) and torch.equal(mx_scales(ops, qs, M, D), mx_scales(ops, s_ref, M, D))
+    # forward (round 6): STATIC scales -- one per 32-column block, the same for every row, from sqrt(D) |gamma| + |beta| (a normalised
+    # row cannot exceed it): block-uniform, nothing saturates, and the bytes are y / 2^e rounded to e4m3
+    sc = mx_scales(ops, qs, M, D)
+    assert bool((sc == sc[0:1]).all())
+    bound = (gamma.abs() * D ** 0.5 + beta.abs()).view(D // 32, 32).amax(dim=1)
+    e_need = torch.ceil(torch.log2(bound / 448)).int() + 127
+    assert bool((sc[0].int() >= e_need).all()) and bool((sc[0].int() <= e_need + 1).all()), (sc[0].int() - e_need)
+    check_block_uniform_form(ops, (q, qs), y, slack=8)
     y_plain = ops.layernorm_fwd(x, gamma, beta, add=add, want_sum=True)[0]
     assert torch.equal(y, y_plain)
     # backward, bf16 gradient stream in place

@@ -40,7 +40,9 @@ for M, shapes in ((1024 * 316, [(1024, 4096), (4096, 1024), (1024, 1024), (3072,
         qr, sr = ops.quant_e4m3_mx(b)
         t_u = timed(lambda: ops.mx_uniform32(qr, sr))          # after the first call every row carries its block's scale: read-only cost
         t_8 = timed(lambda: ops.gemm_tn_e4m3(qa, sa, qb, sb, c))
+        csum = torch.empty(P, device=DEV)
+        t_8c = timed(lambda: ops.gemm_tn_e4m3(qa, sa, qb, sb, c, a_colsum=csum))
         fl = 2.0 * M * P * Q
-        print(f"M={M} P={P} Q={Q}: bf16 {t_bf * 1e3:8.1f} us ({fl / t_bf / 1e9:7.1f} TFLOP/s)   e4m3 {t_8 * 1e3:8.1f} us ({fl / t_8 / 1e9:7.1f} TFLOP/s)   "
+        print(f"M={M} P={P} Q={Q}: bf16 {t_bf * 1e3:8.1f} us ({fl / t_bf / 1e9:7.1f} TFLOP/s)   e4m3 {t_8 * 1e3:8.1f} us ({fl / t_8 / 1e9:7.1f} TFLOP/s; with column sums {t_8c * 1e3:8.1f} us)   "
               f"quant_mx32 of [M, {Q}] {t_q * 1e3:7.1f} us ({3.0 * M * Q / t_q / 1e6:6.0f} GB/s)   uniform32 (no rewrite) {t_u * 1e3:7.1f} us", flush=True)
         del a, b, c, qa, qb, qr

@@ -82,7 +82,6 @@ extern "C" size_t vipant_block_workspace_bytes(int64_t M, int64_t D) {
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, 4 * D, D));
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, 4 * D));
     w = max_sz(w, vipant_gemm_tn_workspace_bytes(M, D, D));
-    w = max_sz(w, vipant_colsum_workspace_bytes(M, 4 * D));         // e4m3 weight gradients: the bias gradients' own pass
     return max_sz(w, vipant_layernorm_bwd_workspace_bytes(M, D));
 }
 
@@ -124,8 +123,7 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
         TRY(operand8(plan->act_q, plan->act_scale, false, dqkv, nullptr, nullptr, M, 3 * D, &aq, &as, stream));
         TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, h, plan->emit_q, plan->emit_scale,
                      M, D, &bq, &bs, stream));
-        TRY(vipant_gemm_tn_e4m3(aq, 3 * D, as, bq, D, bs, dw, D, M, 3 * D, D, 0, workspace, workspace_bytes, stream));
-        TRY(vipant_colsum_bf16(dqkv, 3 * D, db, M, 3 * D, 0, workspace, workspace_bytes, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, 3 * D, as, bq, D, bs, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
     } else {
         TRY(vipant_gemm_tn(dqkv, 3 * D, h, D, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));
     }
@@ -179,7 +177,7 @@ extern "C" int32_t vipant_gemm_bias_residual_bwd_e4m3(const uint16_t* dy, const 
         TRY(operand8(plan->dy_q, plan->dy_scale, false, dy, nullptr, nullptr, M, N, &aq, &as, stream));
         TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, a, plan->act_q, plan->act_scale, M,
                      K, &bq, &bs, stream));
-        return vipant_gemm_tn_e4m3(aq, N, as, bq, K, bs, dw, K, M, N, K, 0, workspace, workspace_bytes, stream);
+        return vipant_gemm_tn_e4m3(aq, N, as, bq, K, bs, dw, K, M, N, K, 0, nullptr, workspace, workspace_bytes, stream);
     }
     return vipant_gemm_tn(dy, N, a, K, dw, K, M, N, K, 0, nullptr, workspace, workspace_bytes, stream);
 }
@@ -203,6 +201,7 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_fwd_e4m3(const void* x, const uint16_
     // with a plan the c_fc epilogue leaves g's e4m3 form (block scales) in the plan's emit buffers and c_proj reads it from there: no
     // quantisation pass over the [M, 4D] activation; `g` / `dcode` may then be NULL (`running.recompute_mlp`: neither is kept)
     const bool emit = plan != nullptr && plan->emit_q != nullptr;
+    // (g == NULL with dcode given, round 6: the e4m3 form and the derivative codes are all the backward will read)
     VIPANT_REQUIRE(emit || (g != nullptr && dcode != nullptr), VIPANT_EBADSHAPE, "ln_mlp_quickgelu_fwd: g and dcode are required");
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->act_q : nullptr,
            plan ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream,
@@ -225,9 +224,12 @@ extern "C" int32_t vipant_mlp_quickgelu_recompute_e4m3(const uint16_t* h, const 
                                                        uint16_t* g, int64_t M, int64_t D, const vipant_fp8_plan* plan,
                                                        void* stream) {
     // h == NULL with a plan: the plan's act_q / act_scale already hold h's e4m3 form (kept from the forward's LayerNorm pass)
+    // (emit_q given, round 6: g's e4m3 form -- what a forward that keeps it would have kept, byte for byte -- is left there; g may be NULL)
     const bool kept = plan != nullptr && h == nullptr;
+    const bool emit = plan != nullptr && plan->emit_q != nullptr;
     return nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, kept ? plan->act_q : nullptr,
-              kept ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream);
+              kept ? plan->act_scale : nullptr, h, w_fc, g, b_fc, dcode, M, 4 * D, D, VIPANT_EPI_QUICKGELU_D8, stream,
+              emit ? plan->emit_q : nullptr, emit ? plan->emit_scale : nullptr);
 }
 
 extern "C" int32_t vipant_mlp_quickgelu_recompute(const uint16_t* h, const uint16_t* w_fc, const float* b_fc, uint8_t* dcode,
@@ -250,8 +252,11 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
     // (VIPANT_STREAM_FEW_ROWS: the operator runs on a batch's read-out rows -- bf16 only: the e4m3 contractions have one kernel)
     const int32_t few = (plan == nullptr && (stream_flags & VIPANT_STREAM_FEW_ROWS)) ? VIPANT_EPI_FEW_ROWS : 0;
     const bool emit = plan != nullptr && plan->emit_q != nullptr;     // du's e4m3 form straight from the epilogue that makes du
+    // (e4m3 weight gradients: nothing reads du's bf16 form any more -- c_fc^T and both users of du in the weight-gradient contraction
+    // take the e4m3 form, the bias gradient rides on that contraction -- so it is not written: `du` may be NULL then)
+    const bool du_q_only = tn8(plan, D) && plan->dy_q != nullptr;
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, plan ? plan->dy_q : nullptr,
-           plan ? plan->dy_scale : nullptr, dy, w_proj_t, du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
+           plan ? plan->dy_scale : nullptr, dy, w_proj_t, du_q_only ? nullptr : du, nullptr, const_cast<uint8_t*>(dcode), M, 4 * D, D,
            VIPANT_EPI_DQUICKGELU_D8 | few, stream, emit ? plan->emit_q : nullptr, emit ? plan->emit_scale : nullptr));
     // dh = du . W_fc;  dW_fc = du^T h, d b_fc = column sums of du
     // (Order, round 5: both input-gradient contractions first, then both weight gradients.  The NT kernels walk their tiles by
@@ -267,12 +272,12 @@ extern "C" int32_t vipant_ln_mlp_quickgelu_bwd_e4m3(const uint16_t* dy, const ui
         TRY(operand8(plan->dy_q, plan->dy_scale, false, dy, nullptr, nullptr, M, D, &aq, &as, stream));
         TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, g, plan->act_q, plan->act_scale, M,
                      4 * D, &bq, &bs, stream));
-        TRY(vipant_gemm_tn_e4m3(aq, D, as, bq, 4 * D, bs, dw_proj, 4 * D, M, D, 4 * D, 0, workspace, workspace_bytes, stream));
-        TRY(operand8(plan->emit_q, plan->emit_scale, false, du, nullptr, nullptr, M, 4 * D, &aq, &as, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, D, as, bq, 4 * D, bs, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
+        TRY(operand8(plan->emit_q, plan->emit_scale, true /* the epilogue's form is block-uniform */, du, nullptr, nullptr, M, 4 * D, &aq,
+                     &as, stream));
         TRY(operand8(const_cast<uint8_t*>(plan->keep2_q), const_cast<uint8_t*>(plan->keep2_scale), true, h, plan->act_q, plan->act_scale,
                      M, D, &bq, &bs, stream));
-        TRY(vipant_gemm_tn_e4m3(aq, 4 * D, as, bq, D, bs, dw_fc, D, M, 4 * D, D, 0, workspace, workspace_bytes, stream));
-        TRY(vipant_colsum_bf16(du, 4 * D, db_fc, M, 4 * D, 0, workspace, workspace_bytes, stream));
+        TRY(vipant_gemm_tn_e4m3(aq, 4 * D, as, bq, D, bs, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));
     } else {
         TRY(vipant_gemm_tn(dy, D, g, 4 * D, dw_proj, 4 * D, M, D, 4 * D, 0, nullptr, workspace, workspace_bytes, stream));
         TRY(vipant_gemm_tn(du, 4 * D, h, D, dw_fc, D, M, 4 * D, D, 0, db_fc, workspace, workspace_bytes, stream));

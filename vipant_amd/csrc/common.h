@@ -164,6 +164,19 @@ __device__ __forceinline__ uint32_t mx_lane_max_u(uint32_t v) {
     if (NL == 8) v = max(v, (uint32_t)__shfl_xor((int)v, 4, 64));
     return v;
 }
+// maximum over the whole wave of a non-negative value (or of |float| bits, which order like the value): four DPP row operations and
+// four readlanes -- no LDS traffic, and the result is wave-uniform (a scalar for what follows)
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+#define VIPANT_MAXU(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xF, 0xF, false))
+    VIPANT_MAXU(0xB1);                          // quad_perm [1, 0, 3, 2]
+    VIPANT_MAXU(0x4E);                          // quad_perm [2, 3, 0, 1]
+    VIPANT_MAXU(0x141);                         // row_half_mirror: the other quad of the 8
+    VIPANT_MAXU(0x140);                         // row_mirror: the other 8 of the 16
+#undef VIPANT_MAXU
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
 // the block's maximum |.| as bf16 bits -> its scale byte (E8M0) and the float 2^e the conversion divides by
 // (round 6: an ALL-ZERO block carries the smallest scale there is, byte 0 = 2^-127, and converts with 2^0 -- not byte 127 as a block
 // whose largest element is ~1 does: vipant_mx_uniform32 takes the maximum of 32 rows' scales, and a row of zeros -- 960 of the 992 rows

@@ -395,17 +395,46 @@ __device__ __forceinline__ void load_codes(const GemmNT& p, int m0, int n0, int 
 // `pre`: the codes of round 0, requested by the caller during the tile's last K-tile (QuickGELU' launch on the DEEP schedule: the
 // HBM round trip of the first round's codes is then off the epilogue's critical path), or NULL
 // EMIT: 0 = the bf16 result only; 1 = also its e4m3 form (p.cq, p.cqs); 2 = the e4m3 form ALONE (QuickGELU epilogue of a tower that
-// keeps neither g nor the derivative codes: their arithmetic is not compiled in)
+// keeps neither g nor the derivative codes: their arithmetic is not compiled in); 3 = the e4m3 form and the derivative codes, no bf16
+// result (round 6: the e4m3 form is all the backward reads of g -- the weight-gradient contraction takes it as it is)
 template <int EPI, int EMIT = 0>
 __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4], const f32x4 (&bv)[4], char* stg, char* stg_hi,
                                             int m0, int n0, int grp, int wl, int frow, int fq, int tid,
-                                            const u32x2 (*pre)[4] = nullptr) {
-    // EMIT: 8 consecutive bf16 results of row m from column n on (n % 8 == 0; the four threads of a 32-column block are four
-    // consecutive lanes, all inside the bounds together since N % 32 == 0) -> e4m3 bytes + the block's scale (MX layout, common.h)
-    auto emit8 = [&](const bf16x8& val, int m, int n, int ch) {
+                                            const u32x2 (*pre)[4] = nullptr, uint32_t* xch = nullptr) {
+    // EMIT (round 6): the e4m3 form carries BLOCK-UNIFORM scales -- one per aligned block of 32 rows x 32 columns, the operand format of
+    // the weight-gradient contraction (vipant_gemm_tn_e4m3), and as good a scale for each of the block's rows in the NT contraction that
+    // reads this matrix next.  The scale comes from a BOUND the wave has in registers before anything is staged: a block is row tiles
+    // 2 r, 2 r + 1 x column tiles 2 jp, 2 jp + 1 of one wave, |QuickGELU(u)| <= |u| and |QuickGELU'| <= 1.1, so max |acc + bias|
+    // (x 1.1) over the wave bounds the block's results (at most a binade above the exact maximum: e4m3's relative precision does not
+    // care, its 15 binades of normal range barely).  One wave reduction per block, all eight of a tile up front; the bytes travel to
+    // the threads that quantise -- another mapping, other waves -- through 32 words per group of the B slot the last K-tile has just
+    // vacated (`xch`), published by the staging barrier of round 0: no barrier of their own.
+    if (EMIT) {
+        constexpr bool DGELU = EPI == VIPANT_EPI_DQUICKGELU || EPI == VIPANT_EPI_DQUICKGELU_D8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float b = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const f32x4 u = acc[2 * r + ii][2 * jp + jj] + bv[2 * jp + jj];
+                        b = fmaxf(fmaxf(b, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
+                    }
+                // (DPP + readlane reduction: the result is a scalar, and so is everything derived from it)
+                const float bw = __uint_as_float(wave_max_u(__float_as_uint(b))) * (DGELU ? 1.11f : 1.01f);    // (+ 1 %: the two roundings to bf16 on the way)
+                float unused;
+                const uint32_t byte = mx_scale_of_max((__float_as_uint(bw) + 0xFFFFu) >> 16, &unused);     // bf16 bits, rounded up
+                if ((tid & 63) == 0) xch[r * 8 + wl * 2 + jp] = byte;
+            }
+    }
+    // 8 consecutive bf16 results of row m from column n on (n % 8 == 0), `blk` = their 32-column block inside the tile's 256 columns
+    auto emit8 = [&](const bf16x8& val, int m, int n, int ch, int r) {
         const u32x4 w = __builtin_bit_cast(u32x4, val);
-        float sc;
-        const uint32_t byte = mx_scale_byte<4>(mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w[0]), w[1]), w[2]), w[3]), &sc);
+        const uint32_t byte = xch[r * 8 + (ch >> 2)];
+        const float sc = byte ? __uint_as_float(byte << 23) : 1.0f;
         *(int2*)(p.cq + (int64_t)m * p.N + n) = int2{mx_pack4_bf16(w[0], w[1], sc), mx_pack4_bf16(w[2], w[3], sc)};
         if ((ch & 3) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)byte;
     };
@@ -496,15 +525,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                                 w = __builtin_amdgcn_cvt_pk_u8_f32(c[1], (uint32_t)((e + 1) & 3), w);
                             }
                         }
-                        if (EMIT != 2) *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
+                        if (EMIT < 2) *(bf16x8*)((bf16_t*)p.C + o + h * 8) = g;
                     }
                     if (EMIT != 2) *(u32x4*)((uint8_t*)p.aux + o) = u32x4{cw[0], cw[1], cw[2], cw[3]};
                     if (EMIT) {         // 16 columns per thread: two threads per 32-column block
                         const u32x4 w0 = __builtin_bit_cast(u32x4, g2[0]), w1 = __builtin_bit_cast(u32x4, g2[1]);
-                        uint32_t mx = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(0u, w0[0]), w0[1]), w0[2]), w0[3]);
-                        mx = mx_absmax2(mx_absmax2(mx_absmax2(mx_absmax2(mx, w1[0]), w1[1]), w1[2]), w1[3]);
-                        float sc;
-                        const uint32_t byte = mx_scale_byte<2>(mx, &sc);
+                        const uint32_t byte = xch[r * 8 + (cp >> 1)];
+                        const float sc = byte ? __uint_as_float(byte << 23) : 1.0f;
                         *(i32x4*)(p.cq + (int64_t)m * p.N + n) = i32x4{mx_pack4_bf16(w0[0], w0[1], sc), mx_pack4_bf16(w0[2], w0[3], sc),
                                                                        mx_pack4_bf16(w1[0], w1[1], sc), mx_pack4_bf16(w1[2], w1[3], sc)};
                         if ((cp & 1) == 0) p.cqs[mx_scale_offset(m, n >> 5, p.N >> 7)] = (uint8_t)byte;
@@ -524,7 +551,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                 const int64_t o = (int64_t)m * p.ldc + n;
                 if (EPI == VIPANT_EPI_BF16) {
                     *(bf16x8*)((bf16_t*)p.C + o) = v;
-                    if (EMIT) emit8(v, m, n, ch);
+                    if (EMIT) emit8(v, m, n, ch, r);
                 } else if (GELU_OUT) {
                     bf16x8 g;
                     uint32_t code[8];
@@ -541,8 +568,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                                                                code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24};
                     else
                         *(bf16x8*)((bf16_t*)p.aux + o) = v;
-                    if (EMIT != 2) *(bf16x8*)((bf16_t*)p.C + o) = g;
-                    if (EMIT) emit8(g, m, n, ch);
+                    if (EMIT < 2) *(bf16x8*)((bf16_t*)p.C + o) = g;
+                    if (EMIT) emit8(g, m, n, ch, r);
                 } else {  // QuickGELU'
                     bf16x8 d;
 #pragma unroll
@@ -557,8 +584,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmNT& p, f32x4 (&acc)[8][4],
                         }
                         d[e] = (bf16_t)((float)v[e] * dg);
                     }
-                    *(bf16x8*)((bf16_t*)p.C + o) = d;
-                    if (EMIT) emit8(d, m, n, ch);
+                    if (EMIT < 2) *(bf16x8*)((bf16_t*)p.C + o) = d;      // (EMIT 2: the e4m3 form alone -- the weight-gradient contraction and c_fc^T read that)
+                    if (EMIT) emit8(d, m, n, ch, r);
                 }
             }
         }
@@ -1015,7 +1042,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
             tickets::post_g(mbox + 4 * tk_par, tk_post);
             if (!tk_dry && !tk_half) tk_pend = tickets::take_g(tkq, (uint32_t)tk_n);      // not awaited here
         }
-        pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr);
+        // (safe for the e4m3 kernels only: their B fragments are read in a K-tile's FIRST interval and kept, so when the leading group
+        // starts its epilogue the lagging group, one interval behind, is past its last read of that slot)
+        static_assert(EMIT == 0 || (!DEEP && ES == 1), "the e4m3 form's scale words live in the B slot of the last K-tile");
+        pp_epilogue<EPI, EMIT>(p, acc, bv, stg, stg + 16 * 512, cur.m0, cur.n0, grp, wl, frow, fq, tid, PRE_CODES ? &cn_pre : nullptr,
+                               (uint32_t*)(smem + PP_B_BASE + (slot == 0 ? 2 : slot - 1) * PP_B_SLOT) + grp * 32);
         // Every wave requests the word posted ONE epilogue ago (the other parity): the index of the tile after the next.  The request
         // is inline asm: a load hipcc can see would be awaited where it is first used with a wait it cannot count (the epilogue's stores
         // sit behind bounds checks: it would be vmcnt(0), every store's acknowledgement), and anywhere inside the K-loop a load has one
@@ -1384,8 +1415,8 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
     VIPANT_REQUIRE((cq == nullptr) == (cq_scale == nullptr), VIPANT_EBADSHAPE, "gemm_nt_e4m3: cq and cq_scale go together");
     VIPANT_REQUIRE(cq == nullptr || (N % 128 == 0 && (uintptr_t)cq % 16 == 0 && epilogue != VIPANT_EPI_BF16), VIPANT_EBADSHAPE,
                    "gemm_nt_e4m3: the e4m3 form of the result needs N %% 128 == 0, a 16-byte aligned cq and one of the QuickGELU epilogues");
-    VIPANT_REQUIRE(C != nullptr || (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8), VIPANT_EBADSHAPE,
-                   "gemm_nt_e4m3: C may be NULL only when the QuickGELU epilogue leaves the e4m3 form alone");
+    VIPANT_REQUIRE(C != nullptr || (cq != nullptr && (epilogue == VIPANT_EPI_QUICKGELU_D8 || epilogue == VIPANT_EPI_DQUICKGELU_D8)), VIPANT_EBADSHAPE,
+                   "gemm_nt_e4m3: C may be NULL only when one of the QuickGELU epilogues leaves the e4m3 form in its place");
     VIPANT_REQUIRE(256 * lda < (1ll << 31) && 256 * ldb < (1ll << 31), VIPANT_EBADSHAPE, "gemm_nt_e4m3: leading dimension too large");
     const char* var = getenv("VIPANT_GEMM_VARIANT");       // read per call, as in vipant_gemm_nt
     const int fp8_dbg = var ? atoi(var) : 0;
@@ -1405,12 +1436,22 @@ extern "C" int32_t vipant_gemm_nt_e4m3(const uint8_t* A, int64_t lda, const uint
         case VIPANT_EPI_DQUICKGELU_D8:
             VIPANT_REQUIRE((aux != nullptr || (C == nullptr && cq != nullptr)) && (uintptr_t)aux % 16 == 0, VIPANT_EBADSHAPE,
                            "gemm_nt_e4m3: the 8-bit QuickGELU' epilogues need a 16-byte aligned aux (the code matrix)");
-            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && (C == nullptr) != (aux == nullptr)) {
-                vipant_set_error("gemm_nt_e4m3: with cq, C and aux are both given or both NULL");
+            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C != nullptr && aux == nullptr) {
+                vipant_set_error("gemm_nt_e4m3: C without aux (the code matrix)");
                 return VIPANT_EBADSHAPE;
             }
-            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C == nullptr)
+            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C == nullptr && aux == nullptr)
                 return launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 2>(p, s);           // the e4m3 form alone
+            if (cq != nullptr && epilogue == VIPANT_EPI_QUICKGELU_D8 && C == nullptr) {      // the e4m3 form + the codes
+                if (ceil_div(M, BM) * ceil_div(N, BN) >= 256 && ceil_div(N, BN) % 2 == 0 && !(fp8_dbg & 33554432))
+                    return launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 8, 1, 3>(p, s);
+                return launch_pp_variant<VIPANT_EPI_QUICKGELU_D8, 0, 1, 3>(p, s);
+            }
+            if (cq != nullptr && epilogue == VIPANT_EPI_DQUICKGELU_D8 && C == nullptr) {     // QuickGELU': the e4m3 form alone
+                if (ceil_div(M, BM) * ceil_div(N, BN) >= 256 && ceil_div(N, BN) % 2 == 0 && !(fp8_dbg & 33554432))
+                    return launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 8, 1, 2>(p, s);
+                return launch_pp_variant<VIPANT_EPI_DQUICKGELU_D8, 0, 1, 2>(p, s);
+            }
             if (cq != nullptr) {
                 // the column-grouped walk (k-step schedule; half of the weight bytes per XCD): 2186 -> 2149 us and 2329 -> 2305 us at the
                 // ViT-L shape, bit-identical; DEEP on the grouped walk gains nothing here.  Bit 25 of VIPANT_GEMM_VARIANT: the plain walk.

@@ -443,6 +443,7 @@ struct GemmTN8 {
     int M, P, Q;
     int splits, kt_per_split;    // in K-tiles of 128 tokens
     int direct;
+    float* colsum;               // optional [splits * ntq][ntp * 256]: partial column sums of dequant(A) (the bias gradient of the same Linear)
 };
 
 constexpr int BK8 = 128;
@@ -538,29 +539,42 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
     // counted waits that have retired the loads anyway.  Used where they are requested, the loads' full latency -- they are the only
     // HBM round trip of the loop that is not an LDS-DMA -- stood in front of every K-tile's first MFMA: 1755 against 1196 us per launch
     // at [323584, 1024] x [323584, 4096].)
+    // Buffer loads (descriptor + 32-bit lane offset + scalar offset): with plain pointers the lane-dependent 64-bit addresses were two
+    // more register pairs across the K-loop, and once the column sums were added they were spilled -- reloaded at the top of every
+    // K-tile behind a vmcnt(0).  Out-of-range K-tiles read as byte 0; token blocks at or beyond M get 2^0 by a select (their bytes in
+    // the array were never written).
     const int sh = 16 * (qd & 1), hi = qd >> 1;
     struct RawScales { uint32_t a[4], b[2]; };
+    const int64_t tk_groups = ((int64_t)p.M + 127) >> 7;
+    const auto rsSA = make_rsrc(p.sa, (uint32_t)(tk_groups * ktpr_a * 512));
+    const auto rsSB = make_rsrc(p.sb, (uint32_t)(tk_groups * ktpr_b * 512));
+    const uint32_t sv_a = (uint32_t)(hi * 4), sv_b = (uint32_t)((kb_b & 3) * 8 + hi * 4);
     auto request_scales = [&](int kt_global, RawScales& r) {
+        const uint32_t so_a = (uint32_t)((kt_global * ktpr_a + ca) * 512), so_b = (uint32_t)((kt_global * ktpr_b + (kb_b >> 2)) * 512);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r.a[k] = 0x7F7F7F7Fu;
-        r.b[0] = r.b[1] = 0x7F7F7F7Fu;
-        if (kt_global * BK8 + 32 * qd < p.M) {
-            if (a_cols_ok) {
-                const uint32_t* g = (const uint32_t*)(p.sa + ((int64_t)kt_global * ktpr_a + ca) * 512) + hi;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) r.a[k] = g[2 * k];
-            }
-            if (b_cols_ok) {
-                const uint32_t* g = (const uint32_t*)(p.sb + ((int64_t)kt_global * ktpr_b + (kb_b >> 2)) * 512 + (kb_b & 3) * 8) + hi;
-                r.b[0] = g[0]; r.b[1] = g[2];
-            }
-        }
+        for (int k = 0; k < 4; ++k) r.a[k] = __builtin_amdgcn_raw_buffer_load_b32(rsSA, sv_a + 8 * k, so_a, 0);
+        r.b[0] = __builtin_amdgcn_raw_buffer_load_b32(rsSB, sv_b, so_b, 0);
+        r.b[1] = __builtin_amdgcn_raw_buffer_load_b32(rsSB, sv_b + 8, so_b, 0);
     };
     auto scales_ready = [&](RawScales& r, uint32_t& sa_out, uint32_t& sb_out) {
         asm volatile("" : "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.a[2]), "+v"(r.a[3]), "+v"(r.b[0]), "+v"(r.b[1]));
         sa_out = ((r.a[0] >> sh) & 255u) | (((r.a[1] >> sh) & 255u) << 8) | (((r.a[2] >> sh) & 255u) << 16) | (((r.a[3] >> sh) & 255u) << 24);
         sb_out = ((r.b[0] >> sh) & 255u) | (((r.b[1] >> sh) & 255u) << 8);
     };
+    auto scales_valid = [&](int kt_global, uint32_t& sa_io, uint32_t& sb_io) {      // token block in range, columns of the tile in range
+        const bool tok = kt_global * BK8 + 32 * qd < p.M;
+        sa_io = (tok && a_cols_ok) ? sa_io : 0x7F7F7F7Fu;
+        sb_io = (tok && b_cols_ok) ? sb_io : 0x7F7F7F7Fu;
+    };
+
+    // Column sums of A ride along, as in the bf16 kernel: the ntq workgroups that share an A tile take turns (K-tile kt belongs to
+    // workgroup kt % ntq).  Wave wl of a group takes token block wl of the K-tile (rows 32 wl .. + 31): a lane sums 4 columns (one
+    // dword: cs_c = lane & 31) of every second row and applies the block's scale, which lane 16 wl of the wave holds (a readlane).
+    // Four accumulators per lane: eight or sixteen made the K-loop spill.
+    const bool do_colsum = p.colsum != nullptr;
+    const int cs_c = lane & 31, cs_row0 = 32 * wl + (lane >> 5);
+    float cs_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cs_turn = tq;                    // K-tiles until this workgroup's next turn (scalar)
 
     i32x8 fq[4];
     uint32_t sav = 0x7F7F7F7Fu, sbv = 0x7F7F7F7Fu, sav_n = 0x7F7F7F7Fu, sbv_n = 0x7F7F7F7Fu;
@@ -571,8 +585,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
     auto half_ktile = [&](auto hc, uint32_t tA, uint32_t tB) {
         constexpr int h = decltype(hc)::value;
         i32x8 fp[2];
-        auto fragA = [&](int cb) { return lds_read_tr8_quad_raw<1024>(tA + (rdA ^ (uint32_t)(cb << 4))); };
-        auto fragB = [&](int cb) { return lds_read_tr8_quad_raw<2048>(tB + (rdB ^ (uint32_t)(cb << 4))); };
+        // (the twelve fragment addresses are one XOR and one add away from rdA / rdB; laundered per interval so that the compiler forms
+        // them here instead of keeping twelve loop-invariant address registers alive across the K-loop)
+        uint32_t ra = rdA, rb = rdB;
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        auto fragA = [&](int cb) { return lds_read_tr8_quad_raw<1024>(tA + (ra ^ (uint32_t)(cb << 4))); };
+        auto fragB = [&](int cb) { return lds_read_tr8_quad_raw<2048>(tB + (rb ^ (uint32_t)(cb << 4))); };
         if (h == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) fq[j] = fragB(wl * 4 + j);
@@ -596,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
     // prologue: scales and K-tile 0 (and, for group 1, its B rows of K-tile 1)
     request_scales(kt0, raw);
     scales_ready(raw, sav, sbv);                             // awaited before any DMA is in flight
+    scales_valid(kt0, sav, sbv);
     fill_a(0, 0);
     fill_b(0, 0);
     if (grp == 1) {
@@ -616,6 +635,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
         fill_a(stage ^ 1, kt + 1);
         if (grp == 0) fill_b(slot1, kt + 1); else fill_b(slot2, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
+        if (do_colsum && cs_turn == 0) {
+            const char* sA = smem + grp * (2 * PP_A_STAGE) + stage * PP_A_STAGE;
+            const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)sav, wl * 16);         // token block wl: the four column blocks' bytes
+            const float sc = __uint_as_float(((s4 >> (8 * (cs_c >> 3))) & 255u) << 23);        // 2^(byte - 127); byte 0 (an all-zero block): 0
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            // (row m = cs_row0 + 2 i has swizzle (i & 3) | (i >> 3) << 2 -- a constant of the unrolled loop -- so the sixteen addresses
+            // are one lane base XOR a constant, plus a row offset; the base is laundered here so that the compiler forms them inside this
+            // branch instead of keeping sixteen loop-invariant address registers alive across the K-loop, which made it spill)
+            int cs_base = cs_row0 * 128 + ((cs_c >> 2) << 4) + (cs_c & 3) * 4;
+            asm volatile("" : "+v"(cs_base));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int v = *(const int*)(sA + ((cs_base ^ (((i & 3) | ((i >> 3) << 2)) << 4)) + 2 * i * 128));
+                const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
+                part[0] += lo[0]; part[1] += lo[1]; part[2] += hi2[0]; part[3] += hi2[1];
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // four loads in flight at a time: registers, not latency, are scarce here
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs_acc[e] += part[e] * sc;
+        }
         half_ktile(Int<0>{}, tA, tB);
         if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -623,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
         // the next K-tile's scales: requested in front of this K-tile's eight DMA pieces, first used here -- the wait the compiler
         // puts in front of this is vmcnt(8), which leaves those pieces in flight (at the K-tile's end it was vmcnt(0))
         scales_ready(raw, sav_n, sbv_n);
+        scales_valid(kt0 + kt + 1, sav_n, sbv_n);
         half_ktile(Int<1>{}, tA, tB);
         if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -630,11 +670,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_pp_kernel(GemmTN8 p) {
         __builtin_amdgcn_s_barrier();
         slot = slot1;
         sav = sav_n; sbv = sbv_n;
+        cs_turn = cs_turn == 0 ? ntq - 1 : cs_turn - 1;
     }
 #undef VIPANT_TN8_MX
+    // the (unused) fills issued by the last K-tiles must have landed in this group's A stages before they are reused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // column-sum partials: the group's own (now idle) A stages serve as the reduction buffer, [8 row groups][128 columns] fp32 = 4 KiB
+    float* red = (float*)(smem + grp * (2 * PP_A_STAGE));
+    const int tl = tid & 255;
+    if (do_colsum) *(f32x4*)(red + (wl * 2 + (lane >> 5)) * 128 + cs_c * 4) = f32x4{cs_acc[0], cs_acc[1], cs_acc[2], cs_acc[3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (grp == 0) __builtin_amdgcn_s_barrier();          // pairs with group 1's last barrier
+    if (do_colsum && tl < 128) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += red[r * 128 + tl];
+        p.colsum[((int64_t)split * ntq + tq) * (ntp * TP) + p0 + grp * 128 + tl] = sum;
+    }
     // lane holds C[p = p0 + grp*128 + i*16 + (lane&15)][q = q0 + wl*64 + j*16 + (lane>>4)*4 + 0..3]
     const int frow = lane & 15, g = lane >> 4;
     if (p.direct) {
@@ -828,12 +882,13 @@ extern "C" int32_t vipant_gemm_tn(const uint16_t* A, int64_t lda, const uint16_t
 extern "C" size_t vipant_gemm_tn_e4m3_workspace_bytes(int64_t M, int64_t P, int64_t Q) {
     int splits, per;
     plan8(M, P, Q, &splits, &per);
-    return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float);
+    return (size_t)splits * (size_t)(ceil_div(P, TP) * ceil_div(Q, TQ)) * TP * TQ * sizeof(float) +
+           (size_t)splits * (size_t)ceil_div(Q, TQ) * (size_t)ceil_div(P, TP) * TP * sizeof(float);
 }
 
 extern "C" int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb,
-                                       float* C, int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       float* C, int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
     VIPANT_REQUIRE(M > 0 && P > 0 && Q > 0, VIPANT_EBADSHAPE, "gemm_tn_e4m3: empty problem");
     VIPANT_REQUIRE(P % 128 == 0 && Q % 128 == 0, VIPANT_EBADSHAPE, "gemm_tn_e4m3: need P %% 128 == 0 and Q %% 128 == 0 (P=%ld Q=%ld)",
                    (long)P, (long)Q);
@@ -848,7 +903,7 @@ extern "C" int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint
                    "gemm_tn_e4m3: per-split byte range exceeds 4 GiB");
     const size_t need = vipant_gemm_tn_e4m3_workspace_bytes(M, P, Q);
     const int direct = (splits == 1 && !accumulate) ? 1 : 0;
-    if (!direct)
+    if (!direct || a_colsum != nullptr)
         VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= need, VIPANT_ENOWORKSPACE,
                        "gemm_tn_e4m3: workspace too small (%zu < %zu)", workspace_bytes, need);
     static DeviceOnce once;
@@ -858,15 +913,30 @@ extern "C" int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
-    GemmTN8 p{A, B, sa, sb, direct ? C : (float*)workspace, lda, ldb, direct ? ldc : TQ, (int)M, (int)P, (int)Q, splits, per, direct};
+    const size_t slab_bytes = (size_t)splits * (size_t)tiles * TP * TQ * sizeof(float);
+    float* cs_part = a_colsum != nullptr ? (float*)((char*)workspace + slab_bytes) : nullptr;
+    GemmTN8 p{A, B, sa, sb, direct ? C : (float*)workspace, lda, ldb, direct ? ldc : TQ, (int)M, (int)P, (int)Q, splits, per, direct, cs_part};
     hipLaunchKernelGGL(gemm_tn8_pp_kernel, dim3((unsigned)(tiles * splits)), dim3(512), PP_LDS_BYTES, s, p);
     VIPANT_LAUNCH_CHECK();
+    const int cs_parts = (int)(splits * ceil_div(Q, TQ)), cs_stride = (int)(ceil_div(P, TP) * TP);
     if (!direct) {
         const int64_t total4 = tiles * TP * TQ / 4;
         int blocks = (int)ceil_div(total4, 256);
         if (blocks > 2048) blocks = 2048;
+        if (a_colsum != nullptr) {       // one launch for both reductions
+            hipLaunchKernelGGL(gemm_tn_reduce_both_kernel, dim3((unsigned)(blocks + ceil_div(P, 64))), dim3(256), 0, s,
+                               (const float*)workspace, C, ldc, (int)P, (int)Q, splits, accumulate, blocks, (const float*)cs_part, a_colsum,
+                               cs_stride, cs_parts);
+            VIPANT_LAUNCH_CHECK();
+            return VIPANT_OK;
+        }
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, C, ldc, (int)P, (int)Q, splits,
                            accumulate);
+        VIPANT_LAUNCH_CHECK();
+    }
+    if (a_colsum != nullptr) {
+        hipLaunchKernelGGL(gemm_tn_colsum_reduce_kernel, dim3((unsigned)ceil_div(P, 64)), dim3(256), 0, s, (const float*)cs_part, a_colsum,
+                           (int)P, cs_stride, cs_parts, accumulate);
         VIPANT_LAUNCH_CHECK();
     }
     return VIPANT_OK;

@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
         gv[t] = *(const f32x4*)(gamma + (t * 64 + lane) * 4);
         bv[t] = *(const f32x4*)(beta + (t * 64 + lane) * 4);
     }
+    // Q8 (round 6): STATIC scales, one per 32-column block and the same for every row -- block-uniform by construction, which is what the
+    // e4m3 weight-gradient contraction needs of this matrix (vipant_gemm_tn_e4m3), and no reduction over the row at all.  A normalised
+    // row has |xhat| <= sqrt(D - 1), so |y_c| <= sqrt(D) |gamma_c| + |beta_c|: nothing can saturate; the bound is about three binades
+    // above what a typical row needs, which e4m3 pays for only below 2^-6 of the scale's unit (|xhat| < ~1e-3: the subnormal grid).
+    const float sqrt_d = sqrtf((float)D);
     for (int64_t row = wave; row < M; row += nwaves) {
         const XI* xr = x + row * ldx;
         f32x4 v[NV];
@@ -93,7 +98,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const XI* __restrict__ x, i
             if (y32 != nullptr) *(f32x4*)(y32 + off) = o;
             v[t] = o;
         }
-        if (Q8) quant_row_mx<NV>(v, q8 + row * D, q8s, row, lane);
+        if (Q8) {
+            // (the static scales are re-derived from gamma / beta for every row -- a dozen VALU instructions per 32-column block in a
+            // kernel that waits on memory -- rather than kept: four more live registers cost the D = 1024 kernel its fifth wave per
+            // SIMD, 598 -> 665 us per launch)
+            float sd = sqrt_d;
+            asm volatile("" : "+v"(sd));         // (or the compiler hoists the whole derivation out of the row loop again)
+#pragma unroll
+            for (int t = 0; t < NV; ++t) {
+                float b = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b = fmaxf(b, fabsf(gv[t][e]) * sd + fabsf(bv[t][e]));
+                const uint32_t m = mx_lane_max_u<8>((__float_as_uint(b * 1.01f) + 0xFFFFu) >> 16);    // bf16 bits, rounded up; 8 lanes = 32 columns
+                float sc;
+                const uint32_t byte = mx_scale_of_max(m, &sc);
+                const u32x2 w = __builtin_bit_cast(u32x2, f32x4_to_bf16x4(v[t]));
+                *(int*)(q8 + row * D + (t * 64 + lane) * 4) = mx_pack4_bf16(w[0], w[1], sc);
+                if ((lane & 7) == 0) q8s[mx_scale_offset(row, t * 8 + (lane >> 3), NV * 2)] = (uint8_t)byte;
+            }
+        }
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }

@@ -144,8 +144,9 @@ def mx_uniform32(q: torch.Tensor, scale: torch.Tensor):
     return q, scale
 
 
-def gemm_tn_e4m3(a, sa, b, sb, c: torch.Tensor, accumulate: bool = False, ws_name: str = "gemm_tn"):
-    """c[P, Q] (fp32) (+)= dequant(a, sa)^T @ dequant(b, sb): a [M, P], b [M, Q] e4m3 bytes with block-uniform scales."""
+def gemm_tn_e4m3(a, sa, b, sb, c: torch.Tensor, accumulate: bool = False, a_colsum=None, ws_name: str = "gemm_tn"):
+    """c[P, Q] (fp32) (+)= dequant(a, sa)^T @ dequant(b, sb): a [M, P], b [M, Q] e4m3 bytes with block-uniform scales;
+    a_colsum (fp32 [P], optional) (+)= column sums of dequant(a, sa)."""
     assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and sa.dtype == torch.uint8 and sb.dtype == torch.uint8
     _need(c, F32, "gemm_tn_e4m3.c")
     M, P = a.shape
@@ -153,7 +154,7 @@ def gemm_tn_e4m3(a, sa, b, sb, c: torch.Tensor, accumulate: bool = False, ws_nam
     assert b.shape[0] == M and tuple(c.shape) == (P, Q), (a.shape, b.shape, c.shape)
     ws = scratch(ws_name, query("vipant_gemm_tn_e4m3_workspace_bytes", M, P, Q), a.device)
     call("vipant_gemm_tn_e4m3", a.data_ptr(), a.stride(0), sa.data_ptr(), b.data_ptr(), b.stride(0), sb.data_ptr(), c.data_ptr(),
-         c.stride(0), M, P, Q, int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+         c.stride(0), M, P, Q, int(accumulate), _ptr(a_colsum), ws.data_ptr(), ws.numel(), _stream())
     return c
 
 
@@ -664,6 +665,8 @@ class BackboneFn(torch.autograd.Function):
             h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
             mean = torch.empty((M,), dtype=F32, device=dev); rstd = torch.empty((M,), dtype=F32, device=dev)
         fp8 = bool(fp8)
+        keep_q = fp8 and train and FP8_TN and D % 128 == 0      # the forward keeps e4m3 forms for the e4m3 weight-gradient contractions
+        kept_s: List = []           # per full block: the block scales of the kept e4m3 forms
         # (e4m3 towers that do not keep the MLP activations need neither: the c_fc epilogue leaves g's e4m3 form for c_proj and nothing else)
         if not keep_mlp and not fp8:        # u: 8-bit codes of QuickGELU'(pre-activation) -- all the backward needs of it
             u, g = new(4 * D, torch.uint8), new(4 * D)
@@ -691,9 +694,20 @@ class BackboneFn(torch.autograd.Function):
                     h1, qkv = new(D), (None if ctx_alg else new(3 * D))
                     mean1, rstd1 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(2))
                 else:
-                    h1, h2, qkv, y1, y2 = new(D), new(D), new(3 * D), new(D), new(D)
+                    qkv, y1, y2 = new(3 * D), new(D), new(D)
                     mean1, rstd1, mean2, rstd2 = (torch.empty((M,), dtype=F32, device=dev) for _ in range(4))
-                    if keep_mlp:
+                    if keep_q:
+                        # e4m3 weight gradients: of the two LayerNorm outputs and of g the backward reads the e4m3 forms alone (block-
+                        # uniform scales: static ones from the LayerNorm passes, the c_fc epilogue's for g) -- 1 instead of 2 bytes per
+                        # element kept, and the bf16 tensors are never written
+                        h1 = h2 = None
+                        h1q, h2q = (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)), (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev))
+                    else:
+                        h1, h2 = new(D), new(D)
+                    if keep_mlp and keep_q:
+                        u, g = new(4 * D, torch.uint8), None
+                        gq = (new(4 * D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, 4 * D),), dtype=torch.uint8, device=dev))
+                    elif keep_mlp:
                         u, g = new(4 * D, torch.uint8), new(4 * D)
             else:
                 wqkv_b, wo_b, wfc_b, wpr_b = wb_all[4 * l:4 * l + 4] if fp8 else (cached_bf16(w) for w in (wqkv, wo, wfc, wpr))
@@ -750,8 +764,8 @@ class BackboneFn(torch.autograd.Function):
             # ln_1 (+ residual add of the previous block's MLP branch: x <- x + y2_prev) + in_proj
             xs = new(D, SDT) if y_prev is not None else None
             call("vipant_ln_qkv_fwd_e4m3", x.data_ptr(), _ptr(y_prev), _ptr(xs), ln1w.data_ptr(), ln1b.data_ptr(), wqkv_b.data_ptr(),
-                 bqkv.data_ptr(), h1.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D,
-                 C.byref(fp8_plan(q_qkv, None, act)) if fp8 else None, sflags(x), st)
+                 bqkv.data_ptr(), _ptr(h1), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), M, D,
+                 C.byref(fp8_plan(q_qkv, None, h1q if (train and keep_q) else act)) if fp8 else None, sflags(x), st)
             if xs is not None:
                 x = xs
             # (e4m3: the attention kernel leaves its output's e4m3 form in the activation scratch; out_proj reads it from there)
@@ -761,7 +775,7 @@ class BackboneFn(torch.autograd.Function):
                  M, D, D, C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
             # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
             x1 = new(D, SDT)
-            if "gemm_nt" in KERNEL_PROBE:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
+            if "gemm_nt" in KERNEL_PROBE and not fp8:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
                 call("vipant_layernorm_fwd_e4m3", x.data_ptr(), D, ln2w.data_ptr(), ln2b.data_ptr(), h2.data_ptr(), None,
                      mean2.data_ptr(), rstd2.data_ptr(), M, D, y1.data_ptr(), x1.data_ptr(), None, None, sflags(x), st)
                 gemm_nt(h2, wfc_b, g, bias=bfc, aux=u, epi=EPI_QUICKGELU_D8)
@@ -770,24 +784,29 @@ class BackboneFn(torch.autograd.Function):
                 only_q = fp8 and not keep_mlp        # c_proj's operand is all that is wanted of g: neither g nor the codes are written
                 # `recompute_mlp` under e4m3: the LayerNorm output's e4m3 form is kept beside it (M D bytes + scales per block), so
                 # that the backward's c_fc launch needs no quantisation pass either
-                h2q = (torch.empty((M, D), dtype=torch.uint8, device=dev),
-                       torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)) if (fp8 and train and recompute_mlp) else None
+                if not (train and keep_q):
+                    h2q = (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)) if (fp8 and train and recompute_mlp) else None
                 call("vipant_ln_mlp_quickgelu_fwd_e4m3", x.data_ptr(), y1.data_ptr(), x1.data_ptr(), ln2w.data_ptr(), ln2b.data_ptr(),
-                     wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
-                     rstd2.data_ptr(), None if only_q else u.data_ptr(), None if only_q else g.data_ptr(), y2.data_ptr(), M, D,
-                     C.byref(fp8_plan(q_fc, q_pr, h2q or act, emit=emit)) if fp8 else None, sflags(x), st)
+                     wfc_b.data_ptr(), bfc.data_ptr(), wpr_b.data_ptr(), bpr.data_ptr(), _ptr(h2), mean2.data_ptr(),
+                     rstd2.data_ptr(), None if only_q else u.data_ptr(), None if (only_q or g is None) else g.data_ptr(), y2.data_ptr(), M, D,
+                     C.byref(fp8_plan(q_fc, q_pr, h2q or act, emit=(gq if (keep_mlp and keep_q) else emit))) if fp8 else None, sflags(x), st)
             if train:
                 # `recompute_mlp`: the two [M, 4D] MLP activations (16 of the 36 D bytes a block keeps per token) are not
                 # kept; the backward re-runs the c_fc contraction (+1 of a block's 12 contractions) to get them back
-                saved += [x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2] + ([u, g] if keep_mlp else [])
+                saved += [x, mean1, rstd1, h1q[0] if keep_q else h1, qkv, o, lse, x1, mean2, rstd2, h2q[0] if keep_q else h2] + \
+                         ([u, gq[0] if keep_q else g] if keep_mlp else [])
                 if fp8 and recompute_mlp:
                     kept_q.append(h2q)
+                kept_s.append(dict(h1=h1q[1], h2=h2q[1], **({"g": gq[1]} if keep_mlp else {})) if keep_q else {})
             x, y_prev = x1, y2
         x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
             ctx.save_for_backward(*saved, *params)
             ctx.wts = wts
             ctx.kept_q = kept_q
+            ctx.kept_s = kept_s
+            ctx.keep_q = keep_q
+            ctx.tn8 = FP8_TN        # (decided by the forward: the backward must read what that forward kept)
             ctx.meta = (batch, S, bool(causal), L, H, bool(recompute_mlp), fp8, prune)
             ctx.rows = ridx
             ctx.last_ctx = ctx_alg
@@ -848,12 +867,14 @@ class BackboneFn(torch.autograd.Function):
             act, emit = fp8_scratch(M, D, dev), fp8_scratch(M, D, dev)
             if not prune:
                 dyq = quant_e4m3_mx(dx_b)   # from here on every LayerNorm backward leaves the new stream gradient's e4m3 form beside it
-        du = torch.empty((M, 4 * D), dtype=BF16, device=dev)          # scratch shared by all blocks
+        # scratch shared by all blocks (e4m3 weight gradients: du exists in its e4m3 form alone, in `emit`)
+        du = None if (ctx.keep_q and ctx.tn8) else torch.empty((M, 4 * D), dtype=BF16, device=dev)
         dh = torch.empty((M, D), dtype=BF16, device=dev)
         do = torch.empty((M, D), dtype=BF16, device=dev)
         if recompute_mlp:
             u = torch.empty((M, 4 * D), dtype=torch.uint8, device=dev)
-            g = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            g = None if ctx.keep_q else torch.empty((M, 4 * D), dtype=BF16, device=dev)
+            gq_re = fp8_scratch(M, D, dev) if ctx.keep_q else None
         grads: List[Optional[torch.Tensor]] = [None] * (12 * L)
         lg = _LayerGrads([p.shape for p in params[12 * (L - 1):12 * L]], dev)
         # d c_proj.bias of the top block (lower blocks get theirs from ln_1's backward): column sums of the stream gradient, which
@@ -926,32 +947,41 @@ class BackboneFn(torch.autograd.Function):
                 lg = lg_below
                 continue
             x, mean1, rstd1, h1, qkv, o, lse, x1, mean2, rstd2, h2 = saved[ns * l:ns * l + 11]
+            kq = ctx.keep_q          # h1, h2 (and g) are the e4m3 forms the forward kept; their block scales are in ctx.kept_s
             if recompute_mlp:
                 h2q = ctx.kept_q[l] if fp8 else None
+                # (e4m3 weight gradients: the recomputation leaves g's e4m3 form -- the same epilogue, the same bytes as a forward that
+                # keeps it -- and no bf16 g)
                 call("vipant_mlp_quickgelu_recompute_e4m3", None if fp8 else h2.data_ptr(), wfc_b.data_ptr(), bfc.data_ptr(), u.data_ptr(),
-                     g.data_ptr(), M, D, C.byref(fp8_plan(wq4[2], None, h2q)) if fp8 else None, st)
+                     None if kq else g.data_ptr(), M, D, C.byref(fp8_plan(wq4[2], None, h2q, emit=gq_re if kq else None)) if fp8 else None, st)
                 if fp8:
                     ctx.kept_q[l] = None
+                keep = gq_re if kq else None
             else:
                 u, g = saved[ns * l + 11:ns * l + 13]
+                keep = (g, ctx.kept_s[l]["g"]) if kq else None
+            keep2 = (h2, ctx.kept_s[l]["h2"]) if kq else None
+            keep1 = (h1, ctx.kept_s[l]["h1"]) if kq else None
             # MLP half: c_proj^T + QuickGELU', c_fc^T, both weight gradients, ln_2 backward (+ residual gradient);
             # the produced stream gradient is also d(out_proj output): its column sum is d out_proj.bias
-            call("vipant_ln_mlp_quickgelu_bwd_e4m3", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(), g.data_ptr(),
-                 h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
-                 du.data_ptr(), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
+            call("vipant_ln_mlp_quickgelu_bwd_e4m3", dx_b.data_ptr(), wpr_t.data_ptr(), wfc_t.data_ptr(), u.data_ptr(),
+                 None if keep else g.data_ptr(),
+                 None if keep2 else h2.data_ptr(), x1.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2w.data_ptr(), _ptr(dx), dx_b.data_ptr(),
+                 _ptr(du), dh.data_ptr(), d_wpr.data_ptr(), d_wfc.data_ptr(), d_bfc.data_ptr(), d_ln2w.data_ptr(),
                  d_ln2b.data_ptr(), d_bo.data_ptr(), M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None, _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
+                 C.byref(fp8_plan(wtq4[3], wtq4[2], act, dyq, emit=emit, tn=ctx.tn8, keep=keep, keep2=keep2)) if fp8 else None,
+                 _ffi.STREAM_IN_F16 if x1.dtype == F16 else 0, st)
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
-                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None, st)
+                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq, emit=emit, tn=ctx.tn8)) if fp8 else None, st)
             q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal, q8=q8)
-            call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
+            call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), None if keep1 else h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
                  rstd1.data_ptr(), ln1w.data_ptr(), _ptr(dx), dx_b.data_ptr(), dh.data_ptr(), d_wqkv.data_ptr(),
                  d_bqkv.data_ptr(), d_ln1w.data_ptr(), d_ln1b.data_ptr(),
                  lg_below.views[11].data_ptr() if lg_below is not None else None, M, D, ws.data_ptr(), ws.numel(),
-                 C.byref(fp8_plan(wtq4[0], None, act, dyq, emit=emit, tn=FP8_TN)) if fp8 else None,
+                 C.byref(fp8_plan(wtq4[0], None, act, dyq, emit=emit, tn=ctx.tn8, keep=keep1)) if fp8 else None,
                  (_ffi.STREAM_IN_F16 if x.dtype == F16 else 0) | (_ffi.STREAM_ACT_Q if q8 else 0), st)
             del dqkv
             for i, v in enumerate(lg.views):
@@ -959,7 +989,7 @@ class BackboneFn(torch.autograd.Function):
             if ctx.grad_sync is not None:
                 ctx.grad_sync.reduce_async(lg.flat, lg.views, params[12 * l:12 * l + 12])
             lg = lg_below
-        ctx.wts = ctx.wqkv_b_last = ctx.kept_q = None
+        ctx.wts = ctx.wqkv_b_last = ctx.kept_q = ctx.kept_s = None
         need = ctx.needs_input_grad
         patch = ctx.patch_node                      # kept: a second backward over a retained graph hands over again
         if dx is None and need[0]:
