@@ -226,6 +226,11 @@ int32_t vipant_quant_e4m3_mx_cols(const uint16_t* x, int64_t ldx, uint8_t* q, in
 int32_t vipant_quant_e4m3_mx32(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
                                void* stream);
 int32_t vipant_mx_uniform32(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, void* stream);
+/* The same two for K columns (K % 32 == 0) that start at column 32 * kb0 of rows 128 * kt_row elements long in the scale layout; x and q
+ * point at the first of those columns (as vipant_quant_e4m3_mx_cols). */
+int32_t vipant_quant_e4m3_mx32_cols(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                    int64_t kt_row, int64_t kb0, void* stream);
+int32_t vipant_mx_uniform32_cols(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, int64_t kt_row, int64_t kb0, void* stream);
 /* Weight-gradient contraction on e4m3 operands (BASELINE.json configs[4]; the autograd of nn.Linear weight, cvap/module/val.py:500-506,
  * as vipant_gemm_tn): C[P, Q] fp32 (+)= dequant(A, sa)^T dequant(B, sb), reduction over the token dimension M.  A [M, P], B [M, Q]:
  * token-major e4m3 bytes with block-uniform scales (above); lda / ldb = the row length of the quantised matrices (what their scale
@@ -235,8 +240,10 @@ size_t vipant_gemm_tn_e4m3_workspace_bytes(int64_t M, int64_t P, int64_t Q);
 int32_t vipant_gemm_tn_e4m3(const uint8_t* A, int64_t lda, const uint8_t* sa, const uint8_t* B, int64_t ldb, const uint8_t* sb, float* C,
                             int64_t ldc, int64_t M, int64_t P, int64_t Q, int32_t accumulate, float* a_colsum, void* workspace,
                             size_t workspace_bytes, void* stream);
-/* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result -- vipant_quant_e4m3_mx of `out`
- * [M, D] resp. `dqkv` [M, 3 D], bit for bit -- for the contraction that follows (out_proj; in_proj^T).  No reference counterpart
+/* vipant_mha_fwd / vipant_mha_bwd that also leave the e4m3 + block-scale form of their result for the contraction that follows
+ * (out_proj; in_proj^T): `out` [M, D] and the dQ columns of `dqkv` [M, 3 D] -- made by a pass behind the kernel -- in the block-uniform
+ * form (vipant_quant_e4m3_mx32, bit for bit; round 6), the dK | dV columns the streamed backward emits from its own epilogue in the
+ * row-wise form (vipant_quant_e4m3_mx, bit for bit): vipant_mx_uniform32_cols makes those uniform too where a weight gradient wants them.  No reference counterpart
  * (BASELINE.json configs[4]).  The streamed single-pass backward (224 < S <= 320, no mask) emits the dK | dV columns from its own
  * epilogue; everything else -- dQ, the other backward shapes, the forward -- is the stand-alone pass enqueued behind the kernel.
  * H even (D % 128 == 0). */

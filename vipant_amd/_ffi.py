@@ -75,6 +75,8 @@ PROTOTYPES = {
     "vipant_quant_e4m3_mx_cols": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "vipant_quant_e4m3_mx32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _p]),
     "vipant_mx_uniform32": (_i32, [_p, _i64, _p, _i64, _i64, _p]),
+    "vipant_quant_e4m3_mx32_cols": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
+    "vipant_mx_uniform32_cols": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _i64, _p]),
     "vipant_gemm_tn_e4m3_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vipant_gemm_tn_e4m3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "vipant_cast_bf16": (_i32, [_p, _p, _p, _i64, _i64, _p]),

@@ -1387,7 +1387,8 @@ extern "C" int32_t vipant_mha_fwd_e4m3(const uint16_t* qkv, uint16_t* out, float
     VIPANT_REQUIRE(oq != nullptr && oq_scale != nullptr && H % 2 == 0, VIPANT_EBADSHAPE, "mha_fwd_e4m3: need both outputs and an even head count");
     MhaArgs a{(const bf16_t*)qkv, (bf16_t*)out, lse, nullptr, nullptr, nullptr, (int)batch, (int)S, (int)H, 0};
     if (int32_t e = causal ? dispatch<true, false>(a, (hipStream_t)stream) : dispatch<false, false>(a, (hipStream_t)stream)) return e;
-    return vipant_quant_e4m3_mx(out, H * 64, oq, H * 64, oq_scale, batch * S, H * 64, stream);
+    // (block-uniform scales, round 6: the same pass, and the weight-gradient contraction of out_proj reads the form as it is)
+    return vipant_quant_e4m3_mx32(out, H * 64, oq, H * 64, oq_scale, batch * S, H * 64, stream);
 }
 
 extern "C" int32_t vipant_mha_bwd_e4m3(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* lse, float* delta,
@@ -1401,7 +1402,8 @@ extern "C" int32_t vipant_mha_bwd_e4m3(const uint16_t* qkv, const uint16_t* out,
     const bool fused = !causal && S > 224 && S <= 320;         // mha_bwd1s_kernel (launch_bwd)
     if (fused) { a.gq = gq; a.gq_scale = gq_scale; }
     if (int32_t e = causal ? dispatch<true, true>(a, (hipStream_t)stream) : dispatch<false, true>(a, (hipStream_t)stream)) return e;
-    return vipant_quant_e4m3_mx_cols(dqkv, 3 * D, gq, 3 * D, gq_scale, batch * S, fused ? D : 3 * D, 3 * D / 128, 0, stream);
+    // (the columns this pass makes -- dQ, or all three thirds -- get block-uniform scales; the streamed kernel's dK | dV stay row-wise)
+    return vipant_quant_e4m3_mx32_cols(dqkv, 3 * D, gq, 3 * D, gq_scale, batch * S, fused ? D : 3 * D, 3 * D / 128, 0, stream);
 }
 
 #ifdef VIPANT_ATTN_STAMPS

@@ -113,14 +113,23 @@ extern "C" int32_t vipant_ln_qkv_bwd_e4m3(const uint16_t* dqkv, const uint16_t* 
     VIPANT_REQUIRE(workspace_bytes >= vipant_block_workspace_bytes(M, D), VIPANT_ENOWORKSPACE, "ln_qkv_bwd: workspace too small");
     // dh = dqkv . W_qkv  (NT on the transposed weight [D, 3D]); VIPANT_STREAM_ACT_Q: vipant_mha_bwd_e4m3 has left dqkv's e4m3 form
     // in the plan's scratch
-    const bool preq = plan != nullptr && (stream_flags & VIPANT_STREAM_ACT_Q);
+    bool preq = plan != nullptr && (stream_flags & VIPANT_STREAM_ACT_Q);
+    const bool wg8 = tn8(plan, D);
+    if (wg8 && !preq) {      // no producer has quantised dqkv: do it here, block-uniform from the start (one pass serves both contractions)
+        TRY(vipant_quant_e4m3_mx32(dqkv, 3 * D, plan->act_q, 3 * D, plan->act_scale, M, 3 * D, stream));
+        preq = true;
+    } else if (wg8) {
+        // vipant_mha_bwd_e4m3's form: the dQ columns are block-uniform already (its pass makes them so); the dK | dV columns, where
+        // the streamed kernel emitted them row-wise from its epilogue, are made uniform in place (a pass over their scale bytes alone
+        // where they are uniform already)
+        TRY(vipant_mx_uniform32_cols(plan->act_q + D, 3 * D, plan->act_scale, M, 2 * D, 3 * D / 128, D / 32, stream));
+    }
     TRY(nt(plan, plan ? plan->w_q : nullptr, plan ? plan->w_scale : nullptr, preq ? plan->act_q : nullptr,
            preq ? plan->act_scale : nullptr, dqkv, w_qkv_t, dh, nullptr, nullptr, M, D, 3 * D, VIPANT_EPI_BF16, stream));
     // dW_qkv = dqkv^T h, d b_qkv = column sums of dqkv
-    if (tn8(plan, D)) {
+    if (wg8) {
         const uint8_t *aq, *as, *bq, *bs;
-        // (dqkv's row-wise e4m3 form is in the plan's scratch either way: left there by vipant_mha_bwd_e4m3, or by the contraction above)
-        TRY(operand8(plan->act_q, plan->act_scale, false, dqkv, nullptr, nullptr, M, 3 * D, &aq, &as, stream));
+        TRY(operand8(plan->act_q, plan->act_scale, true, dqkv, nullptr, nullptr, M, 3 * D, &aq, &as, stream));
         TRY(operand8(const_cast<uint8_t*>(plan->keep_q), const_cast<uint8_t*>(plan->keep_scale), true, h, plan->emit_q, plan->emit_scale,
                      M, D, &bq, &bs, stream));
         TRY(vipant_gemm_tn_e4m3(aq, 3 * D, as, bq, D, bs, dw, D, M, 3 * D, D, 0, db, workspace, workspace_bytes, stream));

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx_kernel(const bf16_t* __rest
 // the rows, finds one scale per 32 k of a column.  A workgroup takes 32 rows x 256 columns: thread t holds the 16-byte chunk t & 31 of
 // rows (t >> 5) + 8 i; the block maximum goes through DPP (the four chunks of a 32-column block are four lanes) and an 8 x 8 LDS table.
 __global__ __launch_bounds__(256) void quant_e4m3_mx32_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
-                                                              int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K, int nct) {
+                                                              int64_t ldq, uint8_t* __restrict__ scale, int64_t M, int K, int nct,
+                                                              int kt_row, int kb0) {
     __shared__ uint32_t tab[8][8];
     const int t = threadIdx.x, ch = t & 31, rg = t >> 5;
     const int64_t nrt = (M + 31) / 32;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx32_kernel(const bf16_t* __re
             const uint32_t b2 = mx_scale_of_max(bm2, &unused);
             const int64_t row = r0 + (t >> 3);
             const int kb = (int)(tile % nct) * 8 + (t & 7);
-            if (row < M && kb * 32 < K) scale[mx_scale_offset(row, kb, K >> 7)] = (uint8_t)b2;
+            if (row < M && kb * 32 < K) scale[mx_scale_offset(row, kb0 + kb, kt_row)] = (uint8_t)b2;
         }
         (void)byte;
         __syncthreads();
@@ -501,15 +502,14 @@ __global__ __launch_bounds__(256) void quant_e4m3_mx32_kernel(const bf16_t* __re
 // the result falls below e4m3's normal range (values 2^15 below the block's largest, rounded to the subnormal grid).  Rows that
 // already carry the block's scale are not rewritten.
 __global__ __launch_bounds__(256) void mx_uniform32_kernel(uint8_t* __restrict__ q, int64_t ldq, uint8_t* __restrict__ scale, int64_t M,
-                                                           int K, int nct) {
+                                                           int K, int nct, int ktr, int kb0) {
     __shared__ uint32_t tab[8][8];
     const int t = threadIdx.x, ch = t & 31, rg = t >> 5;
     const int64_t nrt = (M + 31) / 32;
-    const int ktr = K >> 7;
     for (int64_t tile = blockIdx.x; tile < nrt * nct; tile += gridDim.x) {
         const int64_t r0 = (tile / nct) * 32;
         const int col = (int)(tile % nct) * 256 + ch * 8;
-        const int kb = col >> 5;
+        const int kb = kb0 + (col >> 5);
         const bool col_ok = col < K;
         uint32_t sb[4], smax = 0u;
 #pragma unroll
@@ -575,26 +575,43 @@ extern "C" int32_t vipant_quant_e4m3_mx(const uint16_t* x, int64_t ldx, uint8_t*
     return vipant_quant_e4m3_mx_cols(x, ldx, q, ldq, scale, M, K, K / 128, 0, stream);
 }
 
-extern "C" int32_t vipant_quant_e4m3_mx32(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
-                                          void* stream) {
-    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx32: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+// K columns (K % 32 == 0) starting at column 32 kb0 of rows that are 128 kt_row elements long in the scale layout (x, q point at the first)
+extern "C" int32_t vipant_quant_e4m3_mx32_cols(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                               int64_t kt_row, int64_t kb0, void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && kb0 >= 0 && kb0 * 32 + K <= kt_row * 128, VIPANT_EBADSHAPE,
+                   "quant_e4m3_mx32: need K %% 32 == 0 inside a row of 128 kt_row elements (M=%ld K=%ld kt_row=%ld kb0=%ld)", (long)M, (long)K,
+                   (long)kt_row, (long)kb0);
     VIPANT_REQUIRE(ldx >= K && ldq >= K && ldx % 8 == 0 && ldq % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr,
                    VIPANT_EALIGN, "quant_e4m3_mx32: misaligned rows");
     const int64_t nct = ceil_div(K, 256), tiles = ceil_div(M, 32) * nct;
     hipLaunchKernelGGL(quant_e4m3_mx32_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K, (int)nct);
+                       (const bf16_t*)x, ldx, q, ldq, scale, M, (int)K, (int)nct, (int)kt_row, (int)kb0);
+    VIPANT_LAUNCH_CHECK();
+    return VIPANT_OK;
+}
+
+extern "C" int32_t vipant_quant_e4m3_mx32(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K,
+                                          void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "quant_e4m3_mx32: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
+    return vipant_quant_e4m3_mx32_cols(x, ldx, q, ldq, scale, M, K, K / 128, 0, stream);
+}
+
+extern "C" int32_t vipant_mx_uniform32_cols(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, int64_t kt_row, int64_t kb0,
+                                            void* stream) {
+    VIPANT_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && kb0 >= 0 && kb0 * 32 + K <= kt_row * 128, VIPANT_EBADSHAPE,
+                   "mx_uniform32: need K %% 32 == 0 inside a row of 128 kt_row elements (M=%ld K=%ld kt_row=%ld kb0=%ld)", (long)M, (long)K,
+                   (long)kt_row, (long)kb0);
+    VIPANT_REQUIRE(ldq >= K && ldq % 8 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr, VIPANT_EALIGN, "mx_uniform32: misaligned rows");
+    const int64_t nct = ceil_div(K, 256), tiles = ceil_div(M, 32) * nct;
+    hipLaunchKernelGGL(mx_uniform32_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream, q, ldq, scale,
+                       M, (int)K, (int)nct, (int)kt_row, (int)kb0);
     VIPANT_LAUNCH_CHECK();
     return VIPANT_OK;
 }
 
 extern "C" int32_t vipant_mx_uniform32(uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M, int64_t K, void* stream) {
     VIPANT_REQUIRE(M > 0 && K > 0 && K % 128 == 0, VIPANT_EBADSHAPE, "mx_uniform32: need K %% 128 == 0 (M=%ld K=%ld)", (long)M, (long)K);
-    VIPANT_REQUIRE(ldq >= K && ldq % 8 == 0 && (uintptr_t)q % 8 == 0 && scale != nullptr, VIPANT_EALIGN, "mx_uniform32: misaligned rows");
-    const int64_t nct = ceil_div(K, 256), tiles = ceil_div(M, 32) * nct;
-    hipLaunchKernelGGL(mx_uniform32_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)stream, q, ldq, scale,
-                       M, (int)K, (int)nct);
-    VIPANT_LAUNCH_CHECK();
-    return VIPANT_OK;
+    return vipant_mx_uniform32_cols(q, ldq, scale, M, K, K / 128, 0, stream);
 }
 
 extern "C" int32_t vipant_quant_e4m3_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scale, int64_t M,

@@ -699,8 +699,10 @@ class BackboneFn(torch.autograd.Function):
                     if keep_q:
                         # e4m3 weight gradients: of the two LayerNorm outputs and of g the backward reads the e4m3 forms alone (block-
                         # uniform scales: static ones from the LayerNorm passes, the c_fc epilogue's for g) -- 1 instead of 2 bytes per
-                        # element kept, and the bf16 tensors are never written
+                        # element kept, and the bf16 tensors are never written; the attention output's e4m3 form (what out_proj reads)
+                        # is kept beside the bf16 one the attention backward needs
                         h1 = h2 = None
+                        oq = (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)) if (H % 2 == 0 and ATTN_EMIT) else None
                         h1q, h2q = (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev)), (new(D, torch.uint8), torch.empty((query("vipant_mx_scale_bytes", M, D),), dtype=torch.uint8, device=dev))
                     else:
                         h1, h2 = new(D), new(D)
@@ -769,10 +771,10 @@ class BackboneFn(torch.autograd.Function):
             if xs is not None:
                 x = xs
             # (e4m3: the attention kernel leaves its output's e4m3 form in the activation scratch; out_proj reads it from there)
-            q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
+            q8 = ((oq if (train and keep_q) else act) if (fp8 and H % 2 == 0 and ATTN_EMIT) else None)
             o, lse = mha_fwd(qkv, batch, S, H, causal, q8=q8)
             call("vipant_gemm_bias_residual_fwd_e4m3", None if q8 else o.data_ptr(), wo_b.data_ptr(), bo.data_ptr(), None, y1.data_ptr(),
-                 M, D, D, C.byref(fp8_plan(q_o, None, act)) if fp8 else None, st)
+                 M, D, D, C.byref(fp8_plan(q_o, None, q8 or act)) if fp8 else None, st)
             # ln_2 (+ residual add of the attention branch) + c_fc + QuickGELU + c_proj
             x1 = new(D, SDT)
             if "gemm_nt" in KERNEL_PROBE and not fp8:     # bench.py times the c_fc launch alone: the same three launches, issued one by one
@@ -797,7 +799,7 @@ class BackboneFn(torch.autograd.Function):
                          ([u, gq[0] if keep_q else g] if keep_mlp else [])
                 if fp8 and recompute_mlp:
                     kept_q.append(h2q)
-                kept_s.append(dict(h1=h1q[1], h2=h2q[1], **({"g": gq[1]} if keep_mlp else {})) if keep_q else {})
+                kept_s.append(dict(h1=h1q[1], h2=h2q[1], o=oq, **({"g": gq[1]} if keep_mlp else {})) if keep_q else {})
             x, y_prev = x1, y2
         x = residual_add(x, y_prev) if y_prev is not None else x
         if train:
@@ -974,7 +976,8 @@ class BackboneFn(torch.autograd.Function):
             # attention half: out_proj^T, attention core, in_proj^T + ln_1 backward; the produced stream gradient is
             # d(c_proj output) of the block below: its column sum is that block's d c_proj.bias
             call("vipant_gemm_bias_residual_bwd_e4m3", dx_b.data_ptr(), wo_t.data_ptr(), o.data_ptr(), do.data_ptr(), d_wo.data_ptr(),
-                 M, D, D, ws.data_ptr(), ws.numel(), C.byref(fp8_plan(wtq4[1], None, act, dyq, emit=emit, tn=ctx.tn8)) if fp8 else None, st)
+                 M, D, D, ws.data_ptr(), ws.numel(),
+                 C.byref(fp8_plan(wtq4[1], None, act, dyq, emit=emit, tn=ctx.tn8, keep=ctx.kept_s[l]["o"] if kq else None)) if fp8 else None, st)
             q8 = act if (fp8 and H % 2 == 0 and ATTN_EMIT) else None
             dqkv = mha_bwd(qkv, o, do, lse, batch, S, H, causal, q8=q8)
             call("vipant_ln_qkv_bwd_e4m3", dqkv.data_ptr(), wqkv_t.data_ptr(), None if keep1 else h1.data_ptr(), x.data_ptr(), mean1.data_ptr(),
