@@ -245,9 +245,11 @@ def test_full_size_at_step():
 
 def test_vit_l_depth_sample_independence(ops):
     """BASELINE.json configs[4] tower (audio ViT-L: 24 blocks, width 1024, 16 heads, S = 316) with e4m3 contractions and recomputed
-    MLP activations: a sample's outputs and input gradients in a 16-clip batch equal, bit for bit, those of 4-clip runs; the weight
-    gradients are the sum over the chunks up to fp32 summation order.  (The row quantiser works per token row, so e4m3 keeps the
-    samples independent.)"""
+    MLP activations: the outputs and input gradients of 8 clips in a 16-clip batch equal, bit for bit, those of an 8-clip run; the
+    weight gradients are the sum over the chunks up to fp32 summation order.  (Round 6: the e4m3 forms carry one scale per 32
+    consecutive TOKEN rows x 32 columns -- what the e4m3 weight-gradient contraction needs -- so a chunk is independent of the rest
+    of the batch when its token count is a multiple of 32: 8 clips x 316 tokens = 79 blocks.  Every per-GPU batch of BASELINE.json,
+    512 or 1024 clips, is such a chunk, which is what keeps N replicas equal to one process.)"""
     import vipant_amd.module as Mod
     layers, width, b16 = 24, 1024, 16
     bb = Mod.TransformerBackbone(NS(layers=layers, skip_attn_mask=True), width=width, ctx_len=None)
@@ -263,14 +265,15 @@ def test_vit_l_depth_sample_independence(ops):
     assert torch.isfinite(yf).all()
     full = {k: p.grad.clone() for k, p in bb.named_parameters()}
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in full.items()}
-    for c in range(0, b16, 4):
+    assert (8 * S) % 32 == 0
+    for c in range(0, b16, 8):
         for p in bb.parameters():
             p.grad = None
-        xs = x[c:c + 4].clone().requires_grad_()
+        xs = x[c:c + 8].clone().requires_grad_()
         ys = bb(xs)
-        ys.backward(gy[c:c + 4])
-        assert torch.equal(ys, yf[c:c + 4]), c
-        assert torch.equal(xs.grad, xf.grad[c:c + 4]), c
+        ys.backward(gy[c:c + 8])
+        assert torch.equal(ys, yf[c:c + 8]), c
+        assert torch.equal(xs.grad, xf.grad[c:c + 8]), c
         for k, p in bb.named_parameters():
             acc[k] += p.grad.double()
     for k in full:
@@ -281,9 +284,10 @@ def test_cfg5_full_size_tower_step(ops):
     """BASELINE.json configs[4]'s tower at FULL size in the driver's own test run ("nothing driver-run has
     allocated that step"): audio ViT-L stack (24 blocks, width 1024, 16 heads), 1024 clips x 316 tokens = 323 584 token rows, e4m3
     contractions with MX block scales, recomputed MLP activations (~150 GB; without recomputation the step fits too, 235 GB:
-    profiles/r5_cfg5_mx.md).  One forward + backward; the first and last four clips' outputs and input gradients equal, bit for bit,
-    those of 4-clip runs (samples are independent through the stack and the block quantiser works inside a token row, so the
-    1024-clip numerics are the ones tests/test_model_gpu.py pins to the reference at small batches)."""
+    profiles/r5_cfg5_mx.md).  One forward + backward; the first and last eight clips' outputs and input gradients equal, bit for bit,
+    those of 8-clip runs (a chunk whose token count is a multiple of 32 -- 8 x 316 -- shares no quantisation block with the rest of
+    the batch, see test_vit_l_depth_sample_independence, so the 1024-clip numerics are the ones tests/test_model_gpu.py pins to
+    the reference at small batches)."""
     import vipant_amd.module as Mod
     if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
         pytest.skip("needs the 288 GB of an MI355X")
@@ -306,14 +310,14 @@ def test_cfg5_full_size_tower_step(ops):
     assert torch.isfinite(yf).all() and torch.isfinite(xf.grad).all()
     for k, p in bb.named_parameters():
         assert torch.isfinite(p.grad).all(), k
-    keep = [(c, yf[c:c + 4].clone(), xf.grad[c:c + 4].clone()) for c in (0, b - 4)]
+    keep = [(c, yf[c:c + 8].clone(), xf.grad[c:c + 8].clone()) for c in (0, b - 8)]
     del yf, xf
     for p in bb.parameters():
         p.grad = None
     torch.cuda.empty_cache()
     for c, y_ref, dx_ref in keep:
-        xs = x[c:c + 4].clone().requires_grad_()
+        xs = x[c:c + 8].clone().requires_grad_()
         ys = bb(xs)
-        ys.backward(gy[c:c + 4])
+        ys.backward(gy[c:c + 8])
         assert torch.equal(ys, y_ref), c
         assert torch.equal(xs.grad, dx_ref), c

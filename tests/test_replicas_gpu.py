@@ -80,7 +80,10 @@ def test_two_replicas_match_single_process(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_two_replicas_match_single_process_with_e4m3_contractions(tmp_path):
-    """`running.fp8_gemm` under replicas: the row quantisation is per sample, so the invariant is untouched."""
+    """`running.fp8_gemm` under replicas.  The e4m3 forms share one scale per 32 consecutive token rows (round 6), so replicas equal one
+    process bit for bit only when a rank's token count is a multiple of 32 -- true of every per-GPU batch in BASELINE.json (512 or 1024
+    clips x 316 tokens); at this test's 8 clips x 31 tokens a rank's blocks sit differently, and the invariant holds to the budget below
+    (the e4m3 rounding of a few boundary rows), as the loss and every parameter do."""
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     fp8 = ("running.fp8_gemm=True",)
     mp.spawn(_run, args=(1, 0, one, "gloo", fp8), nprocs=1, join=True)

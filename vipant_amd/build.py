@@ -62,6 +62,31 @@ def _resource_usage(stderr: str):
     return out
 
 
+def _resource_usage_from_isa(path: str):
+    """The same table from the `.amdgpu_metadata` note of a kept device assembly: under `-save-temps` clang emits no resource-usage
+    remarks (the backend runs as a step of its own), but the note carries every kernel's register, spill and scratch counts."""
+    out, cur = {}, None
+    keys = {".vgpr_count": "VGPRs", ".agpr_count": "AGPRs", ".vgpr_spill_count": "VGPRs Spill", ".sgpr_spill_count": "SGPRs Spill",
+            ".private_segment_fixed_size": "ScratchSize [bytes/lane]", ".group_segment_fixed_size": "LDS Size [bytes/block]"}
+    text = open(path).read()
+    start = text.find(".amdgpu_metadata")
+    if start < 0:
+        return out
+    for entry in text[start:].split("\n  - ")[1:]:                    # one list item per kernel ('.args' items are nested deeper)
+        rec, name = {}, None
+        for line in entry.splitlines():
+            m = re.match(r"\s*(\.[a-z_]+):\s*(\S+)\s*$", line)
+            if not m:
+                continue
+            if m.group(1) == ".name" and line.startswith("    .name"):
+                name = m.group(2)
+            elif m.group(1) in keys and m.group(2).isdigit():
+                rec[keys[m.group(1)]] = int(m.group(2))
+        if name and "VGPRs" in rec:
+            out[name] = rec
+    return out
+
+
 def resource_usage():
     """Per-kernel resource usage of the last build: {source file: {kernel: {field: int}}}."""
     res = {}
@@ -125,11 +150,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         base = os.path.basename(src)
-        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(base, []), "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", _obj(src)]
+        # KEEP_ISA files: `-save-temps=obj` leaves the device assembly of THIS compile beside the object (isa_path) -- the text the ISA
+        # guards check is the text that was assembled into the shipped code, not the output of a second compile
+        keep = ["-save-temps=obj"] if base in KEEP_ISA else []
+        cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(base, []), *keep, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", _obj(src)]
         if verbose:
             print("[vipant_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         usage = _resource_usage(r.stderr)
+        if base in KEEP_ISA and r.returncode == 0 and not usage and os.path.exists(isa_path(base)):
+            usage = _resource_usage_from_isa(isa_path(base))
         other = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not _REMARK_ECHO.match(l))
         if other.strip():
             sys.stderr.write(other + "\n")
@@ -137,9 +167,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise subprocess.CalledProcessError(r.returncode, cmd)
         with open(_obj(src)[:-2] + ".resources.json", "w") as f:
             json.dump(usage, f, indent=0)
-        if base in KEEP_ISA:     # the device assembly of the same flags, kept beside the object (isa_path)
-            subprocess.run([HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(base, []), "--cuda-device-only", "-S", src, "-o", isa_path(base)],
-                           stderr=subprocess.DEVNULL, check=True)
+        if base in KEEP_ISA:
+            if not os.path.exists(isa_path(base)):
+                raise RuntimeError(f"{base}: -save-temps=obj left no device assembly at {isa_path(base)}")
+            for junk in glob.glob(os.path.join(OBJ, base[:-4] + "-h*")) + glob.glob(os.path.join(OBJ, base + "-h*")):
+                if junk != isa_path(base):      # the other intermediates (preprocessed source, bitcode, host side, fat binary)
+                    os.remove(junk)
+            from . import isa_guard
+            try:
+                isa_guard.CHECKS[base](isa_path(base))
+            except AssertionError as e:
+                os.remove(_obj(src))            # no object, no library: a build whose hand-counted waits do not hold must not ship
+                raise RuntimeError(f"ISA guard of {base} failed on this toolchain ({e}); VIPANT_GEMM_VARIANT=4194304 selects the static "
+                                   "tile walk of the NT kernels, the attention guard has no fallback") from e
         for name, u in usage.items():
             if u.get("VGPRs Spill", 0) or u.get("ScratchSize [bytes/lane]", 0):
                 print(f"[vipant_amd.build] WARNING {os.path.basename(src)}: {name} spills "
@@ -147,6 +187,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as pool:
         list(pool.map(compile_one, todo))
+    ver = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    with open(os.path.join(OBJ, "toolchain.json"), "w") as f:          # which compiler the ISA guards were checked against
+        json.dump({"hipcc": HIPCC, "version": ver.strip().splitlines()[:3]}, f, indent=0)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *[_obj(s) for s in sources()]]
     if verbose:
         print("[vipant_amd.build]", " ".join(cmd), flush=True)
