@@ -47,7 +47,7 @@ def tower_fwd_flops(S, kpatch, P, width=D, layers=L, embed=E, last_block_rows=Fa
     return (layers - 1) * full + last + 2 * P * kpatch * width + 2 * width * embed if layers > 0 else 2 * P * kpatch * width + 2 * width * embed
 
 
-PMC_FILE = "profiles/r5_pmc_traffic.json"      # this round's counter passes on the shipped build (tools/round_batch.sh pmc)
+PMC_FILE = "profiles/r6_pmc_traffic.json"      # this round's counter passes on the shipped build (tools/round_batch.sh pmc)
 
 
 def pmc_traffic(M, N, K):
@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--no-full-last-block-check", action="store_true",
                     help="skip the 8 extra steps that report the step time with the full last block beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder-alone", action="store_true", help="skip the 13 extra audio-encoder-only iterations (profiling runs: the "
+                    "per-step kernel tables divide by the number of whole steps)")
     ap.add_argument("--script", choices=["va", "at"], default="va",
                     help="va: BASELINE configs[1]/[3] (the headline; frozen image tower).  at: configs[2] -- audio tower + frozen "
                          "CLIP text tower at L=77, local negatives (run_bimodal_at.sh); extra measurement, not the headline")
@@ -462,7 +464,7 @@ def main():
         out["infonce_alone"]["ms_rank_strip_512_of_4096"] = round(e0.elapsed_time(e1) / 10, 4)
         out["infonce_alone"]["workspace_mb"] = round(_ffi.query("vipant_infonce_workspace_bytes", Bn, E) / 1e6, 1)
         out["infonce_alone"]["workspace_mb_rank_strip"] = round(_ffi.query("vipant_infonce_strip_workspace_bytes", Bn, E, 512) / 1e6, 1)
-        if world == 1:
+        if world == 1 and not args.no_encoder_alone:
             # The quantity north_star's 0.40 bar is defined on: the AUDIO ENCODER's forward + backward alone, the headline's 512 clips --
             # no image tower, InfoNCE against fixed unit embeddings (55 us), no optimizer.  Two counts of the same time: the FLOPs the
             # build executes (last block on its read-out rows) and SURVEY.md 8-D4's full-block count (88.9 T at b = 512).

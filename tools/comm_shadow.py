@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--cfg5", action="store_true", help="BASELINE configs[4]'s tower instead of the headline step: AT script, audio ViT-L "
+                    "(width 1024, 24 blocks), e4m3 contractions; pass --batch 1024.  A block's bucket is 50 MB there: the stand-in holds its "
+                    "CUs for min_us x 50 / 28.4 (ShadowGradSync scales with the bucket)")
     args = ap.parse_args()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import probe_lib
@@ -44,6 +47,15 @@ def main():
           "model.audio.pre_encoder.stride=[16,24] model.image.encoder.layers=12 model.audio.width=768 model.audio.encoder.layers=12 "
           f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
           "running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 running.synthetic_steps=100000 num_gpus=1").split()
+    if args.cfg5:
+        from vipant_amd.monitor import VALMonitor as VAMonitor          # noqa: F811  (the AT trainer)
+        ov = ("+running=trimodal monitor=VALMonitor worker=CVALP mode=ddp eval=False +model/image=vit_val +model/audio=vit_val "
+              "+model/text=transformer_val +model/loss=ce_val +optimizer=standard +running/audio=default "
+              "model.audio.pre_encoder.in_channels=3 model.audio.pre_encoder.stride=[16,24] running.siamese.alive=True "
+              "running.imagine=False model.loss.va=False model.image.encoder.layers=12 model.audio.width=1024 "
+              "model.audio.encoder.layers=24 +running.negatives=local running.fp8_gemm=True "
+              f"running.audio.max_len={T} running.audio.num_mel_bins={Fq} running.batch_size={b} running.epochs=1000 "
+              "running.save_epoch=False running.save_rate=1e9 running.peep_rate=1000000 running.synthetic_steps=100000 num_gpus=1").split()
     cfg = compose(ov)
     cfg.rank = 0
     torch.manual_seed(cfg.seed)
@@ -52,14 +64,19 @@ def main():
     mon.start_time = time.time()
     sync = probe_lib.install(mon, probe_lib.ShadowGradSync())      # the stand-in takes GradSync's place; switched per segment below
     g = torch.Generator().manual_seed(1213)
-    images = torch.randn(b, 3, 224, 224, generator=g).to(dev)
-    audios = torch.randn(b, 1, T, Fq, generator=g).to(dev)
+    text = None
+    if args.cfg5:
+        images, audios, text, _, _ = mon.make_batch(next(iter(mon.dataloader)))
+        text = torch.cat([text, text.new_zeros(text.shape[0], 77 - text.shape[1])], dim=1) if text.shape[1] < 77 else text
+    else:
+        images = torch.randn(b, 3, 224, 224, generator=g).to(dev)
+        audios = torch.randn(b, 1, T, Fq, generator=g).to(dev)
     it = [0]
 
     def run(n):
         for _ in range(n):
             adjust_learning_rate(cfg.optimizer, mon.optimizer, mon.dataloader, it[0] + 10)
-            mon.step(images, audios, None)
+            mon.step(images, audios, text)
             it[0] += 1
 
     def timed(walk, overlap, shadow):
@@ -79,12 +96,14 @@ def main():
     settings += [("ticket", "step", s) for s in ("32:300", "32:900")]
     if args.quick:
         settings = [(w, "block", s) for w in ("ticket", "static") for s in ("0", "32:300")]
+    if args.cfg5:        # the e4m3 NT kernels and the weight-gradient kernels walk statically: one walk, the shadow sizes that matter
+        settings = [("ticket", "block", s) for s in ("0", "16:300", "32:300", "64:300", "32:900")] + [("ticket", "step", "32:300")]
     res = {k: [] for k in settings}
     for r in range(args.rounds):
         for k in settings:
             res[k].append(timed(*k))
             print(k, "%.3f" % res[k][-1], flush=True)
-    base = {w: min(res[(w, "block", "0")]) for w in ("ticket", "static")}
+    base = {w: min(res[(w, "block", "0")]) for w in ("ticket", "static") if (w, "block", "0") in res}
     rows = []
     for k in settings:
         best = min(res[k])

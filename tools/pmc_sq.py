@@ -17,7 +17,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel", "mha_fwd_kernel<20", "mha_bwd1s_kernel", "mha_bwd_dq_kernel<20", "mha_bwd_dkv_kernel<20", "ln_fwd_kernel",
+KEEP = ("gemm_nt_pp_kernel", "gemm_tn_pp_kernel", "gemm_tn8_pp_kernel", "mha_fwd_kernel<20", "mha_bwd1s_kernel", "mha_bwd_dq_kernel<20", "mha_bwd_dkv_kernel<20", "ln_fwd_kernel",
         "ln_bwd_kernel", "nce_tile_kernel")
 
 

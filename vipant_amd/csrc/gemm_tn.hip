@@ -784,10 +784,19 @@ void plan_tiles(int64_t M, int64_t tiles, int* splits, int* kt_per_split) {
     *kt_per_split = (int)per;
 }
 
+// VIPANT_TN_SPLIT=k (experiment, default 1): k times as many, k times shorter workgroups per weight-gradient launch -- several per CU
+// instead of one long one, so that CUs another stream's kernel holds (the replica group's all-reduce) cost a launch 1/k of a workgroup's
+// time at its tail instead of a whole one; the price is k times the partial tiles to write and reduce (profiles/r6_comm_shadow_cfg5.md)
+int64_t split_factor() {
+    const char* e = getenv("VIPANT_TN_SPLIT");
+    const int k = e ? atoi(e) : 1;
+    return k < 1 ? 1 : (k > 8 ? 8 : k);
+}
+
 void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
     const int64_t nk = ceil_div(M, BK);
-    int64_t s = 256 / tiles;
+    int64_t s = 256 / tiles * (tiles <= 256 ? split_factor() : 1);
     if (s < 1) s = 1;
     if (s > nk) s = nk;
     const int64_t per = ceil_div(nk, s);
@@ -799,7 +808,7 @@ void plan(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
 void plan8(int64_t M, int64_t P, int64_t Q, int* splits, int* kt_per_split) {
     const int64_t tiles = ceil_div(P, TP) * ceil_div(Q, TQ);
     const int64_t nk = ceil_div(M, BK8);
-    int64_t s = 256 / tiles;
+    int64_t s = 256 / tiles * (tiles <= 256 ? split_factor() : 1);
     if (s < 1) s = 1;
     if (s > nk) s = nk;
     const int64_t per = ceil_div(nk, s);
