@@ -34,7 +34,10 @@ extern "C" int32_t vipant_device_check(void) {
 }
 
 // The ticket block of a (device, stream) pair (common.h): allocated and zeroed on the pair's first persistent launch, kept for the
-// life of the process.  Returns the counter set this launch uses and, in *other, the set it has to zero for the stream's next one.
+// life of the process.  Contract: the alternation of the two counter sets follows the order in which launches REACH the
+// stream, so ticket launches on one stream must be issued by one host thread at a time (the library's own callers are: one Python
+// thread per process), and such a launch cannot be captured into a hipGraph and replayed -- a replay would reuse a counter set nobody
+// zeroed.  VIPANT_GEMM_VARIANT bit 22 (static walk) lifts both restrictions.  Returns the counter set this launch uses and, in *other, the set it has to zero for the stream's next one.
 uint32_t* vipant_ticket_block(hipStream_t stream, uint32_t** other) {
     struct Block { uint32_t* base; int turn; };
     static std::mutex mu;

@@ -678,7 +678,14 @@ __global__ __launch_bounds__(NW * 64) void nce_strip_grad_kernel(NceWs w, int B,
     }
 }
 
-bool strip_path(int64_t B, int64_t E, int64_t nrows) { return B > ROWS_MAX_B && E == ROWS_E && nrows > 0 && nrows <= ROWS_MAX_B && nrows < B; }
+// (nce_strip_grad_kernel keeps B fp32 log-sum-exps beside 64 KiB of operands in its dynamic LDS: batches whose B * 4 + 64 KiB exceed the
+// CU's 160 KiB -- B above ~24 k -- take the tile path, which has no such limit; VIPANT_NCE_STRIP=0 selects the tile path for A/B, and the
+// workspace query follows the same switch so that a caller sizing by it never comes up short: ADVICE r5)
+bool strip_path(int64_t B, int64_t E, int64_t nrows) {
+    const char* strip_env = getenv("VIPANT_NCE_STRIP");
+    if (strip_env && strip_env[0] == '0') return false;
+    return B > ROWS_MAX_B && E == ROWS_E && nrows > 0 && nrows <= ROWS_MAX_B && nrows < B && (B + 3) / 4 * 16 + 65536 <= 160 * 1024;
+}
 
 }  // namespace
 
@@ -696,8 +703,7 @@ extern "C" int32_t vipant_infonce_fwd_bwd(const float* x1, const float* x2, cons
     VIPANT_REQUIRE(B > 0 && E > 0 && E % 64 == 0, VIPANT_EBADSHAPE, "infonce: need E %% 64 == 0 (B=%ld E=%ld)", (long)B, (long)E);
     VIPANT_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= B, VIPANT_EBADSHAPE,
                    "infonce: bad row slice [%ld, %ld) of %ld", (long)row0, (long)(row0 + nrows), (long)B);
-    const char* strip_env = getenv("VIPANT_NCE_STRIP");
-    const bool strip = strip_path(B, E, nrows) && (dx1 != nullptr || dx2 != nullptr) && !(strip_env && strip_env[0] == '0');
+    const bool strip = strip_path(B, E, nrows) && (dx1 != nullptr || dx2 != nullptr);
     VIPANT_REQUIRE(workspace != nullptr && workspace_bytes >= (strip ? vipant_infonce_strip_workspace_bytes(B, E, nrows)
                                                                       : vipant_infonce_workspace_bytes(B, E)),
                    VIPANT_ENOWORKSPACE, "infonce: workspace too small");
