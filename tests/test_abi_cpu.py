@@ -137,3 +137,32 @@ def test_isa_is_from_the_shipped_compile_and_toolchain_is_recorded():
         assert os.path.exists(s_path) and os.path.getmtime(s_path) <= os.path.getmtime(o_path) + 1.0, name
     tc = json.load(open(os.path.join(build.OBJ, "toolchain.json")))
     assert "version" in tc and tc["version"], tc
+
+
+def test_isa_guards_reject_doctored_assembly(tmp_path):
+    """The guards must FAIL on assembly that breaks what they guard (they run inside the build: a guard that cannot fail protects
+    nothing).  Two edits of the shipped build's own assembly: a copy of the ticket walk's mailbox register right after its asm load
+    (what a spill or a relocation by another hipcc would look like), and an instruction that names one of the attention backward's
+    in-flight AGPRs before the counted wait."""
+    from vipant_amd import build, isa_guard
+    build.build(verbose=False)
+    text = open(build.isa_path("gemm_nt.hip")).read()
+    m = re.search(r"(;+#?ASMSTART\n\s*global_load_dword\s+(v\d+),\s*v\[\d+:\d+\],\s*off\s*\n)", text)
+    assert m, "no asm mailbox load found"
+    bad = tmp_path / "gemm_nt_bad.s"
+    bad.write_text(text.replace(m.group(1), m.group(1) + f"\tv_mov_b32_e32 v1, {m.group(2)}\n", 1))
+    with pytest.raises(AssertionError):
+        isa_guard.check_gemm_nt(str(bad))
+    isa_guard.check_gemm_nt(build.isa_path("gemm_nt.hip"))
+    text = open(build.isa_path("attention.hip")).read()
+    k = re.search(r"^_ZN\S*mha_bwd1s_kernelILi20ELb0E\S*:", text, flags=re.M)
+    body = text[k.start():]
+    loads = [x for x in re.finditer(r"global_load_dwordx4\s+a\[(\d+):(\d+)\][^\n]*\n", body)]
+    assert len(loads) >= 10
+    wait = body.index("s_waitcnt vmcnt(22)")
+    last = [x for x in loads if x.end() < wait][-1]
+    doctored = text[:k.start()] + body[:last.end()] + f"\tv_accvgpr_read_b32 v1, a{last.group(1)}\n" + body[last.end():]
+    bad2 = tmp_path / "attention_bad.s"
+    bad2.write_text(doctored)
+    with pytest.raises(AssertionError):
+        isa_guard.check_attention(str(bad2))
