@@ -269,7 +269,7 @@ def bench_at(args, world, rank, local_rank, dev, use_dist):
                       + tower_fwd_flops(77, 0, 0, width=512, layers=12, last_block_rows=lbr)) + 6.0 * b * b * E
     out = {"metric": "audio_text_pairs_per_sec", "value": round(b * world / (ms * 1e-3), 2), "unit": "pairs/s", "n_gpus": world,
            "ranks": world, "rccl": dist.get_backend() if use_dist else None, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "e4m3 NT contractions, bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
+           "vs_baseline": None, "dtype": ("e4m3 contractions (NT and weight-gradient), bf16 elsewhere" if os.environ.get("VIPANT_FP8_TN", "1") != "0" else "e4m3 NT contractions, bf16 elsewhere") if args.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"AT fine-tuning step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT width "
                                   f"{args.width} / {args.layers}L fwd+bwd + frozen CLIP text tower (L=77) fwd + InfoNCE(al) + LARS, local "
                                   "negatives (BASELINE.json configs[2]; configs[4]'s tower with --width 1024 --layers 24, bf16 weights); "
@@ -401,7 +401,7 @@ def main():
         "n_gpus": world, "ranks": world, "rccl": dist.get_backend() if use_dist else None,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "e4m3 NT contractions, bf16 elsewhere (NOT the headline precision)" if args.fp8 else "bf16", "data": "synthetic",
+        "dtype": "e4m3 contractions, bf16 elsewhere (NOT the headline precision)" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"VA pretrain step, per-GPU batch {b}, {Fq}-bin x {T}-frame spectrograms (S={S}), audio ViT-{'B' if W == 768 else W}/{args.layers}L "
                                "fwd+bwd + frozen CLIP ViT-B/32 image tower fwd + InfoNCE + LARS (BASELINE.json configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": b * world, "tokens_per_sample": int(S), "parallelism": f"dp{world}",
