@@ -45,7 +45,7 @@ def _run(rank, world, port, out, backend="gloo", extra=()):
         from vipant_amd.config import compose
         from vipant_amd.module import adjust_learning_rate
         from vipant_amd.monitor import VAMonitor
-        B = 16
+        B = int(os.environ.get("VIPANT_TEST_GLOBAL_BATCH", "16"))
         b = B // world
         cfg = compose(OV + [f"running.batch_size={b}"] + list(extra))
         cfg.rank = 0
@@ -94,6 +94,26 @@ def test_two_replicas_match_single_process_with_e4m3_contractions(tmp_path):
         pa, pb = a["params"][k], b["params"][k]
         err = float((pa - pb).abs().max())
         assert err <= 1e-6 + 2e-4 * float(pa.abs().max()), (k, err)
+
+
+@pytest.mark.timeout(900)
+def test_two_replicas_e4m3_on_block_aligned_ranks(tmp_path, monkeypatch):
+    """The claim of DESIGN.md section 6 (i): when a rank's token count is a multiple of 32 -- here 32 clips x 31 tokens = 31 blocks, as
+    512 x 316 and 1024 x 316 are -- a rank's e4m3 quantisation blocks are the blocks the one-process run has at the same rows, and
+    two replicas take the one-process step as tightly as the bf16 towers do (fp32 summation order of the reduced gradients)."""
+    monkeypatch.setenv("VIPANT_TEST_GLOBAL_BATCH", "64")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    fp8 = ("running.fp8_gemm=True",)
+    mp.spawn(_run, args=(1, 0, one, "gloo", fp8), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), two, "gloo", fp8), nprocs=2, join=True)
+    a, b = torch.load(one), torch.load(two)
+    assert abs(a["loss"] - b["loss"]) < 1e-6, (a["loss"], b["loss"])
+    worst = 0.0
+    for k in a["params"]:
+        pa, pb = a["params"][k], b["params"][k]
+        worst = max(worst, float((pa - pb).abs().max()) / max(float(pa.abs().max()), 1e-30))
+    print(f"e4m3, block-aligned ranks: loss {a['loss']:.7f} / {b['loss']:.7f}, worst parameter difference {worst:.2e} of its scale")
+    assert worst <= 2e-5, worst
 
 
 @pytest.mark.timeout(900)
